@@ -1,0 +1,349 @@
+"""CPU oracle for the CP2 hot path -- TEST INFRASTRUCTURE ONLY.
+
+This file is a CPU (torch fp32 / numpy) restatement of the arithmetic on the
+reference's copy-paste-contrastive hot path (kimathikaai/CP2 builder.py
+`MODEL.forward_cp2` / `forward_densecl` and tools/correlation_mapping.py).
+It is the *checker* for the HIP kernels in cp2_amd/csrc: only `tests/`,
+`__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may import
+it.  Nothing under `cp2_amd/` imports it and nothing here is a fallback for
+the product path.
+
+Parity pin: every function here is checked against golden vectors produced by
+running the reference's own code in the build container
+(tests/golden/make_goldens.py -> tests/golden/*.npz, tests/test_oracle_golden.py)
+and against the reference's known-answer tests
+(tests/test_correlation_mapping.py:65-77,118-130, tests/test_contrastive_metrics.py:17-57).
+
+All citations `file:line` are relative to the reference repository root.
+The functions are encoder-free: they take feature maps (b, C, h, w) as input
+so kernels can be checked without the ResNet in the loop.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------
+# a1: copy-paste composition                          builder.py:1146-1152
+# --------------------------------------------------------------------------
+def compose_mask(img: torch.Tensor, bg: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Foreground mask = pixels where background channel 0 is exactly zero;
+    composed image = img * mask + bg (mask broadcast over the 3 channels)."""
+    fg = torch.eq(bg[:, 0], 0).to(torch.float32)
+    out = torch.add(torch.mul(img, fg[:, None]), bg)
+    return out, fg
+
+
+# --------------------------------------------------------------------------
+# a2: centre-tap strided down-sample    builder.py:1155-1186, loader.py:39-43
+# --------------------------------------------------------------------------
+def strided_gather(x: torch.Tensor, stride: int) -> torch.Tensor:
+    """x[..., s//2::s, s//2::s] on the last two axes."""
+    o = stride // 2
+    return x[..., o::stride, o::stride]
+
+
+# --------------------------------------------------------------------------
+# a4: masked IoU of two id maps          tools/correlation_mapping.py:103-138
+# --------------------------------------------------------------------------
+def masked_iou(map_a, map_b, mask_a, mask_b) -> torch.Tensor:
+    """Per sample: keys = float32(id + 1) * mask over the concatenation of both
+    maps (plus one leading zero); union = #distinct keys - 1 (the zero key);
+    intersection = #distinct non-zero keys seen at least twice.
+
+    The reference carries ids through float32 (torch.cat with a float zero
+    column promotes int64 ids), so ids >= 2**24 may collide; that behaviour is
+    kept.  A sample whose keys are all zero divides 0/0: the reference raises
+    ZeroDivisionError there, the oracle returns NaN for that sample.
+    """
+    a = np.asarray(torch.as_tensor(map_a).reshape(len(map_a), -1).cpu())
+    b = np.asarray(torch.as_tensor(map_b).reshape(len(map_b), -1).cpu())
+    ma = np.asarray(torch.as_tensor(mask_a).reshape(len(mask_a), -1).cpu(), dtype=np.float32)
+    mb = np.asarray(torch.as_tensor(mask_b).reshape(len(mask_b), -1).cpu(), dtype=np.float32)
+    out = np.zeros(a.shape[0], dtype=np.float32)
+    for n in range(a.shape[0]):
+        ka = (a[n] + 1).astype(np.float32) * ma[n]
+        kb = (b[n] + 1).astype(np.float32) * mb[n]
+        keys = np.concatenate([np.zeros(1, np.float32), ka, kb])
+        vals, counts = np.unique(keys, return_counts=True)
+        union = len(vals) - 1
+        inter = int(np.count_nonzero(counts[1:] > 1))
+        out[n] = np.float32(inter / union) if union > 0 else np.float32("nan")
+    return torch.from_numpy(out)
+
+
+# --------------------------------------------------------------------------
+# a3: id-equality correlation map        tools/correlation_mapping.py:141-189
+# --------------------------------------------------------------------------
+def correlation_map(map_a: torch.Tensor, map_b: torch.Tensor) -> Dict[str, torch.Tensor]:
+    n = map_a.shape[0]
+    fa = map_a.reshape(n, -1)
+    fb = map_b.reshape(n, -1)
+    same = fa[:, :, None] == fb[:, None, :]           # (n, P, P) bool
+    ones_a = torch.ones(fa.shape, dtype=torch.float32)
+    ones_b = torch.ones(fb.shape, dtype=torch.float32)
+    return {
+        "corr_map": same,
+        "corr_map_a": same.sum(2),
+        "corr_map_b": same.sum(1),
+        "iou": masked_iou(fa, fb, ones_a, ones_b),
+    }
+
+
+# --------------------------------------------------------------------------
+# a5: masked correlation map             tools/correlation_mapping.py:192-247
+# --------------------------------------------------------------------------
+def masked_correlation_map(map_a, map_b, mask_a, mask_b) -> Dict[str, torch.Tensor]:
+    res = correlation_map(map_a, map_b)
+    n = mask_a.shape[0]
+    fma = mask_a.reshape(n, -1)
+    fmb = mask_b.reshape(n, -1)
+    both = fma[:, :, None] * fmb[:, None, :]
+    corr_mask = res["corr_map"] * both
+    res.update(
+        corr_mask=corr_mask,
+        corr_map_a_masked=corr_mask.sum(2),
+        corr_map_b_masked=corr_mask.sum(1),
+        iou_masked=masked_iou(map_a.reshape(n, -1), map_b.reshape(n, -1), fma, fmb),
+    )
+    return res
+
+
+# --------------------------------------------------------------------------
+# a6: correspondence weights                          builder.py:1225-1243
+# --------------------------------------------------------------------------
+def corr_weights(pixel_corr_map, region_corr_map, region_ids_a, region_ids_b,
+                 w_pixel, w_region, w_not) -> torch.Tensor:
+    """weight = w_pixel where pixel ids match, else w_region where region ids
+    match and both region ids are non-zero, else 0; entries that are still 0
+    then receive w_not.  (All ones for MappingType.CP2.)"""
+    n = region_ids_a.shape[0]
+    known = (region_ids_a.reshape(n, -1)[:, :, None] * region_ids_b.reshape(n, -1)[:, None, :]).bool()
+    region = region_corr_map & known
+    w = w_region * region
+    w = torch.where(pixel_corr_map, torch.as_tensor(w_pixel, dtype=w.dtype), w)
+    w = w + (w == 0) * w_not
+    return w
+
+
+# --------------------------------------------------------------------------
+# a7: per-pixel normalise + masked pooling   builder.py:1261-1268,1279-1285
+# --------------------------------------------------------------------------
+def normalize_and_pool(feat: torch.Tensor, mask: torch.Tensor):
+    """feat (b, C, h, w) or (b, C, P); mask (b, P) of 0/1 floats.
+    Returns dense (b, C, P) unit vectors per pixel, pos = unit(sum over masked
+    pixels), neg = unit(sum over un-masked pixels)."""
+    b, c = feat.shape[:2]
+    dense = F.normalize(feat.reshape(b, c, -1), dim=1)
+    pos = F.normalize(torch.einsum("ncx,nx->nc", dense, mask), dim=1)
+    inv = (~mask.bool()).to(torch.float32)
+    neg = F.normalize(torch.einsum("ncx,nx->nc", dense, inv), dim=1)
+    return dense, pos, neg
+
+
+# --------------------------------------------------------------------------
+# a8/a9: dense logits + dense InfoNCE        builder.py:1289-1292,1392,1431-1437
+# --------------------------------------------------------------------------
+def dense_logits(q_dense, k_dense) -> torch.Tensor:
+    return torch.einsum("ncx,ncy->nxy", q_dense, k_dense)
+
+
+def dense_infonce(logits_dense, mask_a, mask_b, temp_local=1.0, weights=None):
+    """-log_softmax over the QUERY-pixel axis (dim=1 of (n, x, y)), averaged
+    over the positive pairs mask_a[x]*mask_b[y] of each sample, then over the
+    batch.  A sample with no positive pair gives 0/0 = NaN (kept)."""
+    lg = logits_dense if weights is None else logits_dense * weights
+    lg = lg / temp_local
+    nll = -torch.log_softmax(lg, dim=1)
+    labels = mask_a[:, :, None] * mask_b[:, None, :]
+    n = lg.shape[0]
+    per_sample = (nll * labels).reshape(n, -1).sum(1) / labels.reshape(n, -1).sum(1)
+    return per_sample.mean(), per_sample, lg
+
+
+# --------------------------------------------------------------------------
+# a10: instance InfoNCE against the queue    builder.py:1395-1397,1414-1428
+# --------------------------------------------------------------------------
+def instance_infonce(q_pos, k_pos, queue, temp_global=0.2, q_neg=None, k_neg=None,
+                     include_background=False):
+    l_pos = (q_pos * k_pos).sum(1, keepdim=True)
+    l_neg = q_pos @ queue
+    parts = [l_pos, l_neg]
+    if include_background:
+        parts.append((q_pos * q_neg).sum(1, keepdim=True))
+        parts.append((q_pos * k_neg).sum(1, keepdim=True))
+    logits = torch.cat(parts, dim=1) / temp_global
+    target = torch.zeros(logits.shape[0], dtype=torch.long)
+    return F.cross_entropy(logits, target), logits, l_pos, l_neg
+
+
+# --------------------------------------------------------------------------
+# a15: logging statistics
+# --------------------------------------------------------------------------
+def dense_loss_stats(logits_dense, labels_dense):
+    """Per-sample mean and quartiles of positive / negative pair scores.
+    tools/correlation_mapping.py:11-53 (nanmean / nanquantile, linear interp)."""
+    qs = torch.tensor([0.25, 0.5, 0.75])
+
+    def stats(x):
+        return {"average": x.nanmean((1, 2)), "quartiles": torch.nanquantile(x.flatten(1), qs, dim=1)}
+
+    pos = torch.where(labels_dense.bool(), logits_dense, torch.tensor(float("nan")))
+    neg = torch.where(labels_dense.bool(), torch.tensor(float("nan")), logits_dense)
+    return {"positive": stats(pos), "negative": stats(neg)}
+
+
+def instance_stats(l_neg):
+    """builder.py:1399-1406: row mean and row quartiles of the queue logits."""
+    return l_neg.mean(1), torch.quantile(l_neg, torch.tensor([0.25, 0.5, 0.75]), dim=1)
+
+
+def topk_accuracy(logits, target, topk=(1, 5)):
+    """builder.py:1690-1706."""
+    kmax = max(topk)
+    pred = logits.topk(kmax, dim=1).indices          # (n, kmax)
+    hit = pred == target[:, None]
+    return [hit[:, :k].any(1).float().sum() * (100.0 / logits.shape[0]) for k in topk]
+
+
+def dense_argmax_accuracy(logits_dense_scaled, mask_a, mask_b):
+    """builder.py:1442-1448: label at the flat arg-max pair of each sample."""
+    n = logits_dense_scaled.shape[0]
+    labels = (mask_a[:, :, None] * mask_b[:, None, :]).reshape(n, -1)
+    idx = logits_dense_scaled.reshape(n, -1).argmax(1)
+    return labels[torch.arange(n), idx].float().mean() * 100.0
+
+
+# --------------------------------------------------------------------------
+# whole CP2 loss section (everything after the encoders)  builder.py:1145-1448
+# --------------------------------------------------------------------------
+def cp2_loss_section(q_feat, k_feat, bg0, bg1, pixel_ids_a, pixel_ids_b, region_ids_a,
+                     region_ids_b, queue, *, output_stride, temp_global=0.2, temp_local=1.0,
+                     lmbd_dense=0.2, include_background=False,
+                     w_pixel=1, w_region=1, w_not=1, with_stats=False):
+    """Everything forward_cp2 computes from encoder outputs to the loss.
+    q_feat/k_feat: (b, C, h', w') encoder outputs (k already un-shuffled)."""
+    mask_a = strided_gather(torch.eq(bg0[:, 0], 0).float(), output_stride)
+    mask_b = strided_gather(torch.eq(bg1[:, 0], 0).float(), output_stride)
+    pa, pb = strided_gather(pixel_ids_a, output_stride), strided_gather(pixel_ids_b, output_stride)
+    ra, rb = strided_gather(region_ids_a, output_stride), strided_gather(region_ids_b, output_stride)
+    pix = masked_correlation_map(pa, pb, mask_a, mask_b)
+    reg = masked_correlation_map(ra, rb, mask_a, mask_b)
+    w = corr_weights(pix["corr_map"], reg["corr_map"], ra, rb, w_pixel, w_region, w_not)
+    b = q_feat.shape[0]
+    fma, fmb = mask_a.reshape(b, -1), mask_b.reshape(b, -1)
+    q_dense, q_pos, q_neg = normalize_and_pool(q_feat, fma)
+    with torch.no_grad():
+        k_dense, k_pos, k_neg = normalize_and_pool(k_feat, fmb)
+    raw = dense_logits(q_dense, k_dense)
+    loss_ins, logits_moco, l_pos, l_neg = instance_infonce(
+        q_pos, k_pos, queue, temp_global, q_neg, k_neg, include_background)
+    loss_den, loss_den_per_sample, lg_scaled = dense_infonce(raw, fma, fmb, temp_local, w)
+    loss = loss_ins + loss_den * lmbd_dense
+    out = dict(mask_a=fma, mask_b=fmb, pixel_ids_a=pa, pixel_ids_b=pb, region_ids_a=ra, region_ids_b=rb,
+               iou=reg["iou"], iou_masked=reg["iou_masked"], pixel_iou=pix["iou"],
+               pixel_iou_masked=pix["iou_masked"], corr_weights=w,
+               q_dense=q_dense, k_dense=k_dense, q_pos=q_pos, k_pos=k_pos, q_neg=q_neg, k_neg=k_neg,
+               logits_dense_raw=raw, logits_moco=logits_moco, l_pos=l_pos, l_neg=l_neg,
+               loss_instance=loss_ins, loss_dense=loss_den, loss_dense_per_sample=loss_den_per_sample,
+               loss=loss)
+    if with_stats:
+        labels = fma[:, :, None] * fmb[:, None, :]
+        out["dense_stats"] = dense_loss_stats(raw.detach(), labels)
+        out["instance_neg_mean"], out["instance_neg_quartiles"] = instance_stats(l_neg.detach())
+        tgt = torch.zeros(b, dtype=torch.long)
+        out["acc1"], out["acc5"] = topk_accuracy(logits_moco.detach(), tgt)
+        out["acc_dense"] = dense_argmax_accuracy(lg_scaled.detach(), fma, fmb)
+    return out
+
+
+# --------------------------------------------------------------------------
+# a11: momentum (EMA) update of the key encoder          builder.py:557-567
+# --------------------------------------------------------------------------
+def momentum_update(params_k: Sequence[torch.Tensor], params_q: Sequence[torch.Tensor], m: float):
+    """theta_k <- theta_k * m + theta_q * (1 - m); two products then one sum,
+    each rounded to fp32 (no fused multiply-add); the scalar (1.0 - m) is
+    formed in double precision first, exactly as the reference's Python does."""
+    one_minus = 1.0 - m
+    return [pk * m + pq * one_minus for pk, pq in zip(params_k, params_q)]
+
+
+def ema_scalars(m: float) -> Tuple[np.float32, np.float32]:
+    """The two fp32 multipliers the EMA uses: fp32(m), fp32(1.0 - m)."""
+    return np.float32(m), np.float32(1.0 - m)
+
+
+# --------------------------------------------------------------------------
+# a13: queue enqueue with wrap-around                    builder.py:569-587
+# --------------------------------------------------------------------------
+def dequeue_and_enqueue(queue: torch.Tensor, ptr: int, keys: torch.Tensor) -> Tuple[torch.Tensor, int]:
+    """queue (C, K): key i goes to column (ptr + i) mod K; returns the new queue
+    and the advanced pointer.  keys (n, C) are already gathered over ranks."""
+    c, k = queue.shape
+    n = keys.shape[0]
+    assert n <= k
+    cols = (ptr + torch.arange(n)) % k
+    out = queue.clone()
+    out[:, cols] = keys.t()
+    return out, (ptr + n) % k
+
+
+# --------------------------------------------------------------------------
+# a12: shuffle-BN index plan                             builder.py:609-649
+# --------------------------------------------------------------------------
+def shuffle_take(x_gather: torch.Tensor, idx_shuffle: torch.Tensor, rank: int, world: int):
+    """Rows of the all-gathered batch this rank feeds to its key encoder."""
+    return x_gather[idx_shuffle.view(world, -1)[rank]]
+
+
+def unshuffle_take(k_gather: torch.Tensor, idx_shuffle: torch.Tensor, rank: int, world: int):
+    """Rows of the all-gathered keys that restore this rank's original order."""
+    idx_unshuffle = torch.argsort(idx_shuffle)
+    return k_gather[idx_unshuffle.view(world, -1)[rank]]
+
+
+# --------------------------------------------------------------------------
+# a16: DenseCL losses (config 5)                          builder.py:760-910
+# --------------------------------------------------------------------------
+def contrastive_head(pos, neg, temperature):
+    """builder.py:150-176: CE over [pos | neg] / T with target 0."""
+    logits = torch.cat([pos, neg], dim=1) / temperature
+    return F.cross_entropy(logits, torch.zeros(pos.shape[0], dtype=torch.long))
+
+
+def densecl_global_loss(q_global, k_global, queue, temp_global=0.2):
+    """builder.py:760-772."""
+    pos = (q_global * k_global).sum(1, keepdim=True)
+    return contrastive_head(pos, q_global @ queue, temp_global)
+
+
+def densecl_local_loss(q_embed, k_embed, q_local, k_local, q_pixel_ids, k_pixel_ids, queue2,
+                       temp_local=0.2, lmbd_coordinate=0.0):
+    """builder.py:808-910.  q_embed/k_embed (b, Cb, S2) and q_local/k_local
+    (b, C, S2) are unit-normalised over the channel axis; pixel ids (b, s, s).
+    Positive of query pixel x = local similarity with the key pixel that
+    maximises the BACKBONE similarity; where the id maps overlap that score
+    is mixed with the summed local similarity over id-matching key pixels."""
+    backbone_sim = torch.einsum("ncx,ncy->nxy", q_embed, k_embed)
+    best = backbone_sim.argmax(dim=2)                         # (b, S2)
+    local_sim = torch.einsum("ncx,ncy->nxy", q_local, k_local)
+    pos = torch.gather(local_sim, 2, best[:, :, None])[:, :, 0]
+    corr = correlation_map(q_pixel_ids, k_pixel_ids)["corr_map"]
+    overlap = corr.sum(-1) > 0
+    coord = (local_sim * corr).sum(-1)
+    pos = torch.where(overlap, pos * (1 - lmbd_coordinate) + coord * lmbd_coordinate, pos)
+    b, c, s2 = q_local.shape
+    rows = q_local.permute(0, 2, 1).reshape(b * s2, c)
+    neg = rows @ queue2
+    loss = contrastive_head(pos.reshape(-1, 1), neg, temp_local)
+    return loss, pos, neg, best
+
+
+def queue_infonce(rows, pos, queue, temperature):
+    """The rows-vs-queue InfoNCE on its own (T19): mean_r [lse_r - pos_r/T]."""
+    return contrastive_head(pos.reshape(-1, 1), rows @ queue, temperature)
