@@ -1,0 +1,68 @@
+"""ctypes binding of libcp2hip.so (the C ABI declared in include/cp2hip.h)."""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcp2hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "cp2hip.h")
+
+_P = c_void_p  # every device pointer crosses the ABI as a plain address
+
+# name -> argument ctypes (return type is int unless listed in _RESTYPE)
+SIGNATURES = {
+    "cp2_version": [],
+    "cp2_error_string": [c_int],
+    "cp2_compose_mask": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
+    "cp2_strided_gather_f32": [_P, _P, c_int, c_int, c_int, c_int, _P],
+    "cp2_strided_gather_i64": [_P, _P, c_int, c_int, c_int, c_int, _P],
+    "cp2_gather_rows_f32": [_P, _P, _P, c_int, c_int, c_int64, _P, _P],
+    "cp2_corr_iou": [_P, _P, _P, _P, _P, _P, c_int, c_int, _P],
+    "cp2_ema_flat": [_P, _P, c_int64, c_float, c_float, _P],
+    "cp2_ema_multi": [_P, _P, _P, _P, _P, c_int, c_float, c_float, _P],
+    "cp2_enqueue": [_P, _P, _P, c_int, c_int, c_int, _P],
+}
+_RESTYPE = {"cp2_error_string": c_char_p}
+
+_lib = None
+
+
+class Cp2LibraryError(RuntimeError):
+    pass
+
+
+def declared_symbols(header: str = HEADER_PATH):
+    """Names of every function declared in include/cp2hip.h."""
+    text = open(header).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cp2_[a-z0-9_]+)\s*\(", text)))
+
+
+def load() -> ctypes.CDLL:
+    """Load libcp2hip.so or fail loudly -- there is no fallback implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Cp2LibraryError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C cp2_amd/csrc`).  cp2_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise Cp2LibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPE.get(name, c_int)
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().cp2_error_string(rc)
+        raise Cp2LibraryError(f"{what} failed with code {rc}: {msg.decode() if msg else '?'}")

@@ -1,0 +1,16 @@
+// Library-level entry points of libcp2hip.so.
+#include <hip/hip_runtime.h>
+#include "../../include/cp2hip.h"
+
+extern "C" __attribute__((visibility("default"))) int cp2_version(void) { return 100; }
+
+extern "C" __attribute__((visibility("default"))) const char* cp2_error_string(int code) {
+    switch (code) {
+        case CP2_OK: return "ok";
+        case CP2_ERR_NULL: return "a required pointer is NULL";
+        case CP2_ERR_SHAPE: return "a size is zero, negative or inconsistent";
+        case CP2_ERR_UNSUPPORTED: return "size outside the supported range of this kernel";
+        case CP2_ERR_ALIGN: return "pointer is not 16-byte aligned";
+        default: return code > 0 ? hipGetErrorString(static_cast<hipError_t>(code)) : "unknown cp2 error";
+    }
+}

@@ -1,0 +1,159 @@
+"""GPU: bit-exact parity of the integer / mask / copy kernels with the oracle and
+with the golden vectors recorded from the reference (through the C ABI)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cp2_amd import ops
+from oracle import cp2_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name + ".npz")))
+
+
+def G(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def synth_bg(b, h, w, gen):
+    bg = torch.rand(b, 3, h, w, generator=gen)
+    for n in range(b):
+        rh, rw = int(h * 0.6), int(w * 0.7)
+        y0 = int(torch.randint(0, h - rh + 1, (1,), generator=gen))
+        x0 = int(torch.randint(0, w - rw + 1, (1,), generator=gen))
+        bg[n, :, y0:y0 + rh, x0:x0 + rw] = 0.0
+    return bg
+
+
+@pytest.mark.parametrize("name", ["cp2_b4_64_k64", "cp2_b4_96_k64_wrap_bg", "cp2_b3_80x112_k1024"])
+def test_compose_and_gathers_golden(golden_dir, name):
+    g = load(golden_dir, name)
+    stride = int(g["cfg"][4])
+    out, mfull, mds = ops.compose_mask(G(g["in_img_a"]), G(g["in_bg0"]), stride, want_full_mask=True)
+    assert np.array_equal(out.cpu().numpy(), g["img_a"])
+    b = out.shape[0]
+    assert np.array_equal(mds.reshape(b, -1).cpu().numpy(), g["mask_a"])
+    assert np.array_equal(mfull.cpu().numpy(), (g["in_bg0"][:, 0] == 0).astype(np.float32))
+    for k in ("pixel_ids_a", "pixel_ids_b", "region_ids_a", "region_ids_b"):
+        assert np.array_equal(ops.strided_gather(G(g["in_" + k]), stride).cpu().numpy(), g[k]), k
+    _, _, mds_b = ops.compose_mask(G(g["in_img_b"]), G(g["in_bg1"]), stride)
+    assert np.array_equal(mds_b.reshape(b, -1).cpu().numpy(), g["mask_b"])
+    # a3-a5 on the down-sampled maps
+    iou, ioum = ops.corr_iou(G(g["region_ids_a"]), G(g["region_ids_b"]), G(g["mask_a"]), G(g["mask_b"]))
+    assert np.array_equal(iou.cpu().numpy(), g["iou"]) and np.array_equal(ioum.cpu().numpy(), g["iou_masked"])
+    iou, ioum = ops.corr_iou(G(g["pixel_ids_a"]), G(g["pixel_ids_b"]), G(g["mask_a"]), G(g["mask_b"]))
+    assert np.array_equal(iou.cpu().numpy(), g["pixel_iou"]) and np.array_equal(ioum.cpu().numpy(), g["pixel_iou_masked"])
+
+
+@pytest.mark.parametrize("shape,stride", [((32, 224, 224), 16), ((3, 50, 37), 8), ((2, 17, 21), 1), ((2, 64, 66), 32)])
+def test_compose_full_size_vs_oracle(shape, stride):
+    b, h, w = shape
+    gen = torch.Generator().manual_seed(5)
+    img, bg = torch.rand(b, 3, h, w, generator=gen), synth_bg(b, h, w, gen)
+    img[0, 0, 0, 0] = float("inf")           # inf * 0 must stay NaN exactly as in torch
+    want, mask = O.compose_mask(img, bg)
+    out, mfull, mds = ops.compose_mask(img.to(DEV), bg.to(DEV), stride, want_full_mask=True)
+    assert np.array_equal(out.cpu().numpy(), want.numpy(), equal_nan=True)
+    assert torch.equal(mfull.cpu(), mask)
+    assert torch.equal(mds.cpu(), O.strided_gather(mask, stride))
+    ids = torch.randint(0, 1 << 40, (b, h, w), generator=gen)
+    assert torch.equal(ops.strided_gather(ids.to(DEV), stride).cpu(), O.strided_gather(ids, stride))
+
+
+@pytest.mark.parametrize("tag", ["unique", "shared", "random"])
+def test_corr_iou_kats(golden_dir, tag):
+    g = load(golden_dir, "corrmap_kats")
+    a, b = torch.from_numpy(g[f"{tag}_map_a"]).long(), torch.from_numpy(g[f"{tag}_map_b"]).long()
+    iou, ioum = ops.corr_iou(a.to(DEV), b.to(DEV), G(g[f"{tag}_mask_a"]), G(g[f"{tag}_mask_b"]))
+    assert np.array_equal(iou.cpu().numpy(), g[f"{tag}_iou"])
+    assert np.array_equal(ioum.cpu().numpy(), g[f"{tag}_iou_masked"])
+    if tag == "unique":
+        assert torch.equal(iou.cpu(), torch.ones(4) * (12 / 38)) and torch.equal(ioum.cpu(), torch.ones(4) / 3)
+    if tag == "shared":
+        assert torch.equal(iou.cpu(), torch.tensor([4 / 7])) and torch.equal(ioum.cpu(), torch.tensor([2 / 3]))
+
+
+@pytest.mark.parametrize("B,P,hi", [(32, 196, 60000), (8, 4096, 5000), (5, 1, 3), (4, 1024, 1 << 30), (2, 16383, 100)])
+def test_corr_iou_random_vs_oracle(B, P, hi):
+    gen = torch.Generator().manual_seed(P)
+    a = torch.randint(0, hi, (B, P), generator=gen)
+    b = torch.randint(0, hi, (B, P), generator=gen)
+    ma = (torch.rand(B, P, generator=gen) > 0.3).float()
+    mb = (torch.rand(B, P, generator=gen) > 0.5).float()
+    ma[0] = 0
+    mb[0] = 0                                  # empty masks -> 0/0 -> NaN (reference raises there)
+    iou, ioum = ops.corr_iou(a.to(DEV), b.to(DEV), ma.to(DEV), mb.to(DEV))
+    assert np.array_equal(iou.cpu().numpy(), O.masked_iou(a, b, torch.ones_like(ma), torch.ones_like(mb)).numpy())
+    assert np.array_equal(ioum.cpu().numpy(), O.masked_iou(a, b, ma, mb).numpy(), equal_nan=True)
+    assert torch.isnan(ioum[0])
+
+
+def test_ema_golden_and_full_size(golden_dir):
+    g = load(golden_dir, "queue_ema_shuffle")
+    n = len([k for k in g if k.startswith("ema_q_")])
+    pk = [G(g[f"ema_k0_{i}"]) for i in range(n)]
+    pq = [G(g[f"ema_q_{i}"]) for i in range(n)]
+    plan = ops.EmaMultiPlan(pk, pq)
+    for rnd in (1, 2):
+        plan.run(float(g["ema_m"]))
+        for i in range(n):
+            assert np.array_equal(pk[i].cpu().numpy(), g[f"ema_k{rnd}_{i}"]), (rnd, i)
+    # flat form at encoder scale (66 M floats + a ragged tail), against the oracle
+    gen = torch.Generator().manual_seed(0)
+    N = 66_000_003
+    k, q = torch.randn(N, generator=gen), torch.randn(N, generator=gen)
+    want = O.momentum_update([k], [q], 0.999)[0]
+    kd, qd = k.to(DEV), q.to(DEV)
+    ops.ema_flat(kd, qd, 0.999)
+    assert torch.equal(kd.cpu(), want)
+    # multi-tensor form with ragged, unaligned views
+    base_k, base_q = torch.randn(300_001, generator=gen).to(DEV), torch.randn(300_001, generator=gen).to(DEV)
+    cuts = [0, 1, 66, 70_001, 200_000, 300_001]
+    vk = [base_k[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+    vq = [base_q[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+    want = O.momentum_update([base_k.cpu()], [base_q.cpu()], 0.99)[0]
+    ops.EmaMultiPlan(vk, vq).run(0.99)
+    assert torch.equal(base_k.cpu(), want)
+
+
+def test_enqueue_golden_and_wrap(golden_dir):
+    g = load(golden_dir, "queue_ema_shuffle")
+    for tag in ("plain", "wrap", "exact", "big"):
+        queue, keys = G(g[f"enq_{tag}_queue_before"]), G(g[f"enq_{tag}_keys"])
+        ptr = torch.tensor([int(g[f"enq_{tag}_ptr_before"])], dtype=torch.long, device=DEV)
+        ops.enqueue(queue, keys, ptr)
+        assert np.array_equal(queue.cpu().numpy(), g[f"enq_{tag}_queue_after"]), tag
+        assert int(ptr) == int(g[f"enq_{tag}_ptr_after"]), tag
+    # BASELINE size: K=65536, 256 keys per step, many steps across the wrap point
+    gen = torch.Generator().manual_seed(1)
+    K, C, n = 65536, 128, 256
+    q_cpu = torch.randn(C, K, generator=gen)
+    queue, ptr, p = q_cpu.to(DEV), torch.tensor([K - 3 * n - 7], dtype=torch.long, device=DEV), K - 3 * n - 7
+    for _ in range(5):
+        keys = torch.randn(n, C, generator=gen)
+        q_cpu, p = O.dequeue_and_enqueue(q_cpu, p, keys)
+        ops.enqueue(queue, keys.to(DEV), ptr)
+    assert torch.equal(queue.cpu(), q_cpu) and int(ptr) == p
+
+
+def test_gather_rows_shuffle(golden_dir):
+    g = load(golden_dir, "queue_ema_shuffle")
+    x, perm = G(g["shuf_x"]), torch.from_numpy(g["shuf_perm"]).to(DEV)
+    assert np.array_equal(ops.gather_rows(x, perm).cpu().numpy(), g["shuf_out"])
+    back = ops.gather_rows(G(g["shuf_out"]), torch.from_numpy(g["shuf_idx_unshuffle"]).to(DEV))
+    assert np.array_equal(back.cpu().numpy(), g["shuf_x"])
+    gen = torch.Generator().manual_seed(2)
+    big = torch.rand(64, 3, 224, 224, generator=gen)
+    idx = torch.randperm(64, generator=gen)[:32]
+    assert torch.equal(ops.gather_rows(big.to(DEV), idx.to(DEV)).cpu(), big[idx])
+    odd = torch.rand(9, 7, 5, generator=gen)
+    assert torch.equal(ops.gather_rows(odd.to(DEV), torch.tensor([8, 0, 3], device=DEV)).cpu(), odd[[8, 0, 3]])
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.gather_rows(odd.to(DEV), torch.tensor([9], device=DEV), flag)
+    assert int(flag) == 1
