@@ -1,0 +1,645 @@
+// a8-a10, a16: the contrastive logit kernels, fp32 on the matrix cores.
+//
+// All three contractions of the reference are over the C=128 channel axis of
+// unit-norm feature vectors stored channel-major ([C][n], the reference's own NCHW /
+// [C,K] queue layout), so both MFMA operands are read without any transpose:
+//   v_mfma_f32_32x32x2_f32:  D[i][j] += A[i][k] B[k][j],  lane l: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]
+// f32-input MFMA is an exact fp32 fmaf chain (parity with the fp32 reference to ~1e-6)
+// at 1/16 of the bf16 rate; see DESIGN.md for the split-bf16 plan.
+//
+// "Transposed flash" orientation: the 32 OWNER vectors of a wave (the side whose
+// softmax statistics are kept) sit in registers as the B operand, one owner per lane
+// column; the OTHER side streams through LDS as the A operand.  The accumulator then
+// holds S^T[other][owner] with the owner on the lane, so max / sum-exp / rescale are
+// lane-local, and the accumulator registers are directly the B operand of the second
+// product  U^T[c][owner] += sum_other X[c][other] * P[other][owner]  (no LDS round trip).
+//
+//   rowkey_fwd   owners = rows (pooled q vectors, or DenseCL pixels), others = queue keys
+//                builder.py:1395-1428 (instance InfoNCE), :866-873,906-908 (DenseCL local)
+//   dense_fwd    owners = key pixels y, others = query pixels x of the same sample
+//                builder.py:1289-1292,1392,1431-1437 (column-wise log-softmax, dim=1)
+//   dense_bwd    owners = query pixels x, others = key pixels y: d loss / d q_dense
+#include "common.hpp"
+#include <math.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int CH = 128;  // feature channels (MODEL dim, main.py:404-412)
+
+__device__ __forceinline__ int rho(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// LDS tile T[c][j], j < KT, row pitch KT+1 floats (odd pitch: both the row read of
+// product 1 and the column read of product 2 are bank-conflict free).
+template <int KT>
+__device__ __forceinline__ void fill_tile(float* __restrict__ T, const float* __restrict__ src, int64_t ld, int j0,
+                                          int jmax, int tid) {
+    constexpr int KP = KT + 1;
+#pragma unroll 4
+    for (int e = tid; e < CH * KT; e += 256) {
+        const int c = e / KT, j = e % KT;
+        T[c * KP + j] = (j0 + j < jmax) ? src[(int64_t)c * ld + j0 + j] : 0.f;
+    }
+}
+
+// S^T[other = kk + rho(reg,h)][owner = lane&31] for one 32x32 sub-tile.
+template <int KP>
+__device__ __forceinline__ f32x16 product1(const float* __restrict__ T, int kk, const float (&bq)[CH / 2], int r, int h) {
+    f32x16 acc = {0};
+#pragma unroll
+    for (int t = 0; t < CH / 2; ++t) acc = mfma32(T[(2 * t + h) * KP + kk + r], bq[t], acc);
+    return acc;
+}
+// U^T[c = cb*32 + rho(reg',h)][owner] += sum_other T[c][other] * p[other][owner]
+template <int KP>
+__device__ __forceinline__ void product2(const float* __restrict__ T, int kk, const float (&p)[16], f32x16 (&U)[4], int r,
+                                         int h) {
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+            U[cb] = mfma32(T[(cb * 32 + r) * KP + kk + rho(reg, 0) + 4 * h], p[reg], U[cb]);
+    }
+}
+
+// ===========================================================================
+// rows-vs-queue InfoNCE, forward with fused gradient accumulation
+// ===========================================================================
+struct RowKeyArgs {
+    const float* rows; int RP; int64_t r_sn, r_sx, r_sc; int R;  // row r -> (n=r/RP, x=r%RP), element (c,r) at n*r_sn + x*r_sx + c*r_sc
+    const float* keys; int K;                                     // [CH][K]
+    const float* extras; int NE; float inv_t;                     // raw extra logits [R][NE], column 0 = positive
+    int keys_per_split;
+    float* part_m; float* part_s; int* part_cnt; float* part_U;   // [S][R], [S][R], [S][R], [S][CH][R]
+    float* lnegT;                                                  // optional raw logits, key-major [K][R]
+};
+
+template <int WR, int WK, bool WITH_U>
+__global__ __launch_bounds__(256) void rowkey_fwd_kernel(RowKeyArgs a) {
+    constexpr int NSUB = (WK == 1) ? 2 : 1;
+    constexpr int KT = 32 * WK * NSUB, KP = KT + 1;
+    extern __shared__ __attribute__((aligned(16))) float T[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid / WK, wk = wid % WK, r = lane & 31, h = lane >> 5;
+    const int row0 = (blockIdx.x * WR + wr) * 32, row = row0 + r;
+    const bool row_ok = row < a.R;
+    float bq[CH / 2];
+    {
+        const int rr = row_ok ? row : 0;
+        const float* base = a.rows + (int64_t)(rr / a.RP) * a.r_sn + (int64_t)(rr % a.RP) * a.r_sx;
+#pragma unroll
+        for (int t = 0; t < CH / 2; ++t) bq[t] = row_ok ? base[(int64_t)(2 * t + h) * a.r_sc] : 0.f;
+    }
+    const float pos_s = (row_ok && a.NE > 0) ? a.extras[(int64_t)row * a.NE] * a.inv_t : INFINITY;
+    float m_run = -INFINITY, s_run = 0.f;
+    int cnt = 0;
+    f32x16 U[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) U[cb] = (f32x16){0};
+    const int k_begin = blockIdx.y * a.keys_per_split;
+    const int k_end = min(a.K, k_begin + a.keys_per_split);
+    for (int k0 = k_begin; k0 < k_end; k0 += KT) {
+        __syncthreads();
+        fill_tile<KT>(T, a.keys, a.K, k0, k_end, tid);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) {
+            const int kk = (wk + WK * s) * 32;
+            if (k0 + kk >= k_end) continue;  // wave-uniform
+            const f32x16 acc = product1<KP>(T, kk, bq, r, h);
+            float sv[16];
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int key = k0 + kk + rho(reg, h);
+                const bool valid = key < k_end;
+                if (a.lnegT && valid && row_ok) a.lnegT[(int64_t)key * a.R + row] = acc[reg];
+                sv[reg] = valid ? acc[reg] * a.inv_t : -INFINITY;
+                tmax = fmaxf(tmax, sv[reg]);
+                cnt += (sv[reg] > pos_s) ? 1 : 0;
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            if (__any(tmax > m_run)) {
+                const float m_new = fmaxf(m_run, tmax);
+                const float sc = __expf(m_run - m_new);  // exp(-inf) = 0 on the first tile
+                s_run *= sc;
+                if (WITH_U) {
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) U[cb] *= sc;
+                }
+                m_run = m_new;
+            }
+            float p[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                p[reg] = __expf(sv[reg] - m_run);
+                s_run += p[reg];
+            }
+            if (WITH_U) product2<KP>(T, kk, p, U, r, h);
+        }
+    }
+    const float s_tot = s_run + __shfl_xor(s_run, 32, 64);
+    const int cnt_tot = cnt + __shfl_xor(cnt, 32, 64);
+    const int slot = blockIdx.y;
+    if constexpr (WK == 1) {
+        if (row_ok) {
+            if (h == 0) {
+                a.part_m[(int64_t)slot * a.R + row] = m_run;
+                a.part_s[(int64_t)slot * a.R + row] = s_tot;
+                a.part_cnt[(int64_t)slot * a.R + row] = cnt_tot;
+            }
+            if (WITH_U) {
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg)
+                        a.part_U[((int64_t)slot * CH + cb * 32 + rho(reg, h)) * a.R + row] = U[cb][reg];
+            }
+        }
+    } else {
+        // merge the WK key-waves that share a row tile through LDS, then one coalesced write
+        __syncthreads();
+        float* Ubuf = T;                                  // [WR*WK][CH][32]
+        float* mbuf = T + WR * WK * CH * 32;              // [WR*WK][32]
+        float* sbuf = mbuf + WR * WK * 32;
+        int* cbuf = reinterpret_cast<int*>(sbuf + WR * WK * 32);
+        if (h == 0) mbuf[wid * 32 + r] = m_run;
+        __syncthreads();
+        float M = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < WK; ++j) M = fmaxf(M, mbuf[(wr * WK + j) * 32 + r]);
+        const float f = (m_run == -INFINITY) ? 0.f : __expf(m_run - M);
+        if (h == 0) { sbuf[wid * 32 + r] = s_tot * f; cbuf[wid * 32 + r] = cnt_tot; }
+        if (WITH_U) {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) Ubuf[(wid * CH + cb * 32 + rho(reg, h)) * 32 + r] = U[cb][reg] * f;
+        }
+        __syncthreads();
+        for (int e = tid; e < WR * 32; e += 256) {
+            const int w2 = e / 32, rr = e % 32, grow = (blockIdx.x * WR + w2) * 32 + rr;
+            if (grow < a.R) {
+                float mm = -INFINITY, ss = 0.f;
+                int cc = 0;
+                for (int j = 0; j < WK; ++j) {
+                    mm = fmaxf(mm, mbuf[(w2 * WK + j) * 32 + rr]);
+                    ss += sbuf[(w2 * WK + j) * 32 + rr];
+                    cc += cbuf[(w2 * WK + j) * 32 + rr];
+                }
+                a.part_m[(int64_t)slot * a.R + grow] = mm;
+                a.part_s[(int64_t)slot * a.R + grow] = ss;
+                a.part_cnt[(int64_t)slot * a.R + grow] = cc;
+            }
+        }
+        if (WITH_U) {
+            for (int e = tid; e < WR * CH * 32; e += 256) {
+                const int rr = e % 32, c = (e / 32) % CH, w2 = e / (32 * CH);
+                const int grow = (blockIdx.x * WR + w2) * 32 + rr;
+                if (grow < a.R) {
+                    float u = 0.f;
+                    for (int j = 0; j < WK; ++j) u += Ubuf[((w2 * WK + j) * CH + c) * 32 + rr];
+                    a.part_U[((int64_t)slot * CH + c) * a.R + grow] = u;
+                }
+            }
+        }
+    }
+}
+
+// Merge the per-split partials: lse, per-row loss, count of negatives above the
+// positive, d loss / d row (in the rows' own layout) and d loss / d extra logit.
+struct RowKeyFinArgs {
+    const float* part_m; const float* part_s; const int* part_cnt; const float* part_U; int S;
+    const float* extras; int NE; float inv_t; float grad_scale;
+    int R; int RP; int64_t d_sn, d_sx, d_sc;
+    float* lse; float* loss_rows; int* cnt_gt; float* drows; float* dE;
+};
+
+__global__ __launch_bounds__(256) void rowkey_finalize_kernel(RowKeyFinArgs a) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int row = blockIdx.x * 64 + lane;
+    if (row >= a.R) return;
+    float M = -INFINITY;
+    for (int s = 0; s < a.S; ++s) M = fmaxf(M, a.part_m[(int64_t)s * a.R + row]);
+    float e[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < a.NE; ++j) { e[j] = a.extras[(int64_t)row * a.NE + j] * a.inv_t; M = fmaxf(M, e[j]); }
+    float Z = 0.f;
+    int cnt = 0;
+    for (int s = 0; s < a.S; ++s) {
+        const float ms = a.part_m[(int64_t)s * a.R + row];
+        if (ms != -INFINITY) Z += a.part_s[(int64_t)s * a.R + row] * expf(ms - M);
+        cnt += a.part_cnt[(int64_t)s * a.R + row];
+    }
+    for (int j = 0; j < a.NE; ++j) Z += expf(e[j] - M);
+    const float lse = M + logf(Z);
+    if (w == 0) {
+        a.lse[row] = lse;
+        a.loss_rows[row] = lse - e[0];
+        a.cnt_gt[row] = cnt;
+        if (a.dE)
+            for (int j = 0; j < a.NE; ++j)
+                a.dE[(int64_t)row * a.NE + j] = a.grad_scale * a.inv_t * (expf(e[j] - lse) - (j == 0 ? 1.f : 0.f));
+    }
+    if (!a.drows) return;
+    float acc[CH / 4];
+#pragma unroll
+    for (int i = 0; i < CH / 4; ++i) acc[i] = 0.f;
+    for (int s = 0; s < a.S; ++s) {
+        const float ms = a.part_m[(int64_t)s * a.R + row];
+        if (ms == -INFINITY) continue;
+        const float ws = expf(ms - lse);
+        const float* u = a.part_U + ((int64_t)s * CH + w * (CH / 4)) * a.R + row;
+#pragma unroll
+        for (int i = 0; i < CH / 4; ++i) acc[i] += u[(int64_t)i * a.R] * ws;
+    }
+    float* d = a.drows + (int64_t)(row / a.RP) * a.d_sn + (int64_t)(row % a.RP) * a.d_sx;
+    const float gs = a.grad_scale * a.inv_t;
+#pragma unroll
+    for (int i = 0; i < CH / 4; ++i) d[(int64_t)(w * (CH / 4) + i) * a.d_sc] = acc[i] * gs;
+}
+
+// out[0] = mean(x[0..n)) (single workgroup: deterministic order)
+__global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += x[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (red[0] + red[1] + red[2] + red[3]) / (float)n;
+}
+
+static int rowkey_shape(int R, int* WR, int* WK) {
+    if (R <= 32) { *WR = 1; *WK = 4; }
+    else if (R <= 64) { *WR = 2; *WK = 2; }
+    else { *WR = 4; *WK = 1; }
+    return 0;
+}
+
+CP2_API int cp2_rowkey_num_splits(int R, int K) {
+    // enough workgroups to fill 256 CUs about twice over, at least 4 LDS tiles of keys per split
+    if (R <= 0 || K <= 0) return CP2_ERR_SHAPE;
+    int WR, WK;
+    rowkey_shape(R, &WR, &WK);
+    const int KT = 32 * WK * (WK == 1 ? 2 : 1);
+    const int row_blocks = cp2_cdiv(R, 32 * WR);
+    int ns = cp2_cdiv(512, row_blocks);
+    const int max_ns = cp2_cdiv(K, 4 * KT);
+    if (ns > max_ns) ns = max_ns;
+    if (ns < 1) ns = 1;
+    return ns;
+}
+
+CP2_API int cp2_rowkey_infonce_fwd(const float* rows, int RP, int64_t r_sn, int64_t r_sx, int64_t r_sc, int R,
+                                   const float* keys, int K, const float* extras, int NE, float temperature,
+                                   int nsplit, float* part_m, float* part_s, int32_t* part_cnt, float* part_U,
+                                   float* lnegT, int C, void* stream) {
+    if (!rows || !keys || !part_m || !part_s || !part_cnt) return CP2_ERR_NULL;
+    if (NE > 0 && !extras) return CP2_ERR_NULL;
+    if (R <= 0 || K <= 0 || RP <= 0 || nsplit <= 0 || NE < 0 || NE > 4 || !(temperature > 0.f)) return CP2_ERR_SHAPE;
+    if (C != CH) return CP2_ERR_UNSUPPORTED;
+    int WR, WK;
+    rowkey_shape(R, &WR, &WK);
+    const int KT = 32 * WK * (WK == 1 ? 2 : 1);
+    int kps = cp2_cdiv(K, nsplit);
+    kps = cp2_cdiv(kps, KT) * KT;
+    if ((int64_t)kps * (nsplit - 1) >= K && nsplit > 1) return CP2_ERR_SHAPE;  // an empty split: caller must use cp2_rowkey_num_splits
+    RowKeyArgs a{rows, RP, r_sn, r_sx, r_sc, R, keys, K, extras, NE, 1.0f / temperature, kps,
+                 part_m, part_s, part_cnt, part_U, lnegT};
+    size_t lds = (size_t)CH * (KT + 1) * sizeof(float);
+    if (WK > 1) {
+        const size_t merge = ((size_t)WR * WK * CH * 32 + 3 * (size_t)WR * WK * 32) * sizeof(float);
+        if (merge > lds) lds = merge;
+    }
+    const dim3 grid(cp2_cdiv(R, 32 * WR), nsplit), block(256);
+    const bool wu = part_U != nullptr;
+#define CP2_LAUNCH_RK(wr_, wk_, wu_)                                                                            \
+    do {                                                                                                        \
+        auto kfn = rowkey_fwd_kernel<wr_, wk_, wu_>;                                                            \
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                                 \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
+        if (e_ != hipSuccess) return (int)e_;                                                                   \
+        hipLaunchKernelGGL(kfn, grid, block, lds, cp2_stream(stream), a);                                       \
+    } while (0)
+    if (WR == 1) { if (wu) CP2_LAUNCH_RK(1, 4, true); else CP2_LAUNCH_RK(1, 4, false); }
+    else if (WR == 2) { if (wu) CP2_LAUNCH_RK(2, 2, true); else CP2_LAUNCH_RK(2, 2, false); }
+    else { if (wu) CP2_LAUNCH_RK(4, 1, true); else CP2_LAUNCH_RK(4, 1, false); }
+#undef CP2_LAUNCH_RK
+    return cp2_launch_status();
+}
+
+CP2_API int cp2_rowkey_infonce_finalize(const float* part_m, const float* part_s, const int32_t* part_cnt,
+                                        const float* part_U, int nsplit, const float* extras, int NE,
+                                        float temperature, float grad_scale, int R, int RP, int64_t d_sn,
+                                        int64_t d_sx, int64_t d_sc, float* lse, float* loss_rows, int32_t* cnt_gt,
+                                        float* drows, float* dE, float* loss_mean, int C, void* stream) {
+    if (!part_m || !part_s || !part_cnt || !lse || !loss_rows || !cnt_gt) return CP2_ERR_NULL;
+    if (drows && !part_U) return CP2_ERR_NULL;
+    if (NE > 0 && !extras) return CP2_ERR_NULL;
+    if (R <= 0 || RP <= 0 || nsplit <= 0 || NE < 0 || NE > 4 || !(temperature > 0.f)) return CP2_ERR_SHAPE;
+    if (C != CH) return CP2_ERR_UNSUPPORTED;
+    RowKeyFinArgs a{part_m, part_s, part_cnt, part_U, nsplit, extras, NE, 1.0f / temperature, grad_scale,
+                    R, RP, d_sn, d_sx, d_sc, lse, loss_rows, cnt_gt, drows, dE};
+    hipLaunchKernelGGL(rowkey_finalize_kernel, dim3(cp2_cdiv(R, 64)), dim3(256), 0, cp2_stream(stream), a);
+    int rc = cp2_launch_status();
+    if (rc || !loss_mean) return rc;
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, cp2_stream(stream), loss_rows, R, loss_mean);
+    return cp2_launch_status();
+}
+
+// ===========================================================================
+// dense (pixel-to-pixel) InfoNCE of one sample pair
+// ===========================================================================
+struct DenseArgs {
+    const float* qd; const float* kd;            // [B][CH][P] unit vectors per pixel
+    const float* mask_a; const float* mask_b;    // [B][P]
+    const int64_t* pix_a; const int64_t* pix_b;  // [B][P] or NULL (all weights 1)
+    const int64_t* reg_a; const int64_t* reg_b;
+    float w_pixel, w_region, w_not, inv_t;
+    int P;
+    // forward outputs, per key pixel y: [B][P]
+    float* lse; float* colsum_a; float* possum; float* allsum; float* colmax; int* argx;
+    // backward
+    const float* sample_scal;                    // [B][8]: Sa, Sb, ...
+    float grad_scale; float* g_dense;            // [B][CH][P]
+};
+
+__device__ __forceinline__ float corr_weight(int64_t pa, int64_t pb, int64_t ra, int64_t rb, float wp, float wr, float wn) {
+    // builder.py:1225-1243: pixel match -> w_pixel, else known-region match -> w_region, else 0; zeros become w_not
+    float w = (pa == pb) ? wp : ((ra == rb && ra != 0 && rb != 0) ? wr : 0.f);
+    return w == 0.f ? wn : w;
+}
+
+constexpr int DKT = 64, DKP = DKT + 1;
+struct DenseLds {
+    float T[CH * DKP];
+    float ma[DKT]; float aux[DKT]; float aux2[DKT];
+    int64_t pid[DKT]; int64_t rid[DKT];
+};
+
+// owners = key pixels y (lane), others = query pixels x (LDS tile).  Column-wise softmax
+// statistics over x for every y, the masked column sums, and the logging sums.
+template <bool WEIGHTS>
+__global__ __launch_bounds__(256) void dense_fwd_kernel(DenseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    DenseLds& L = *reinterpret_cast<DenseLds*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int n = blockIdx.y, P = a.P;
+    const int y = (blockIdx.x * 4 + wid) * 32 + r;
+    const bool y_ok = y < P;
+    const float* qd = a.qd + (int64_t)n * CH * P;
+    const float* kd = a.kd + (int64_t)n * CH * P;
+    float bq[CH / 2];
+#pragma unroll
+    for (int t = 0; t < CH / 2; ++t) bq[t] = y_ok ? kd[(int64_t)(2 * t + h) * P + y] : 0.f;
+    int64_t pb = 0, rb = 0;
+    if (WEIGHTS && y_ok) { pb = a.pix_b[(int64_t)n * P + y]; rb = a.reg_b[(int64_t)n * P + y]; }
+    float m_run = -INFINITY, s_run = 0.f, a_run = 0.f, pos_run = 0.f, all_run = 0.f, best_v = -INFINITY;
+    int best_x = 0;
+    for (int x0 = 0; x0 < P; x0 += DKT) {
+        __syncthreads();
+        fill_tile<DKT>(L.T, qd, P, x0, P, tid);
+        if (tid < DKT) {
+            const int x = x0 + tid;
+            L.ma[tid] = x < P ? a.mask_a[(int64_t)n * P + x] : 0.f;
+            if (WEIGHTS) {
+                L.pid[tid] = x < P ? a.pix_a[(int64_t)n * P + x] : -1;
+                L.rid[tid] = x < P ? a.reg_a[(int64_t)n * P + x] : 0;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int kk = s * 32;
+            if (x0 + kk >= P) continue;
+            const f32x16 acc = product1<DKP>(L.T, kk, bq, r, h);
+            float sv[16];
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int xi = kk + rho(reg, h), x = x0 + xi;
+                const bool valid = x < P;
+                const float raw = acc[reg];
+                float w = 1.f;
+                if (WEIGHTS) w = corr_weight(L.pid[xi], pb, L.rid[xi], rb, a.w_pixel, a.w_region, a.w_not);
+                const float v = raw * w * a.inv_t;
+                sv[reg] = valid ? v : -INFINITY;
+                if (valid) {
+                    const float ma = L.ma[xi];
+                    a_run += ma * v;
+                    pos_run += ma * raw;
+                    all_run += raw;
+                    if (v > best_v) { best_v = v; best_x = x; }
+                }
+                tmax = fmaxf(tmax, sv[reg]);
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run, tmax);
+            s_run *= __expf(m_run - m_new);
+            m_run = m_new;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) s_run += __expf(sv[reg] - m_run);
+        }
+    }
+    // combine the two lane halves (they saw disjoint x)
+    s_run += __shfl_xor(s_run, 32, 64);
+    a_run += __shfl_xor(a_run, 32, 64);
+    pos_run += __shfl_xor(pos_run, 32, 64);
+    all_run += __shfl_xor(all_run, 32, 64);
+    const float ov = __shfl_xor(best_v, 32, 64);
+    const int ox = __shfl_xor(best_x, 32, 64);
+    if (ov > best_v || (ov == best_v && ox < best_x)) { best_v = ov; best_x = ox; }
+    if (y_ok && h == 0) {
+        const int64_t o = (int64_t)n * P + y;
+        a.lse[o] = m_run + logf(s_run);
+        a.colsum_a[o] = a_run;
+        a.possum[o] = pos_run;
+        a.allsum[o] = all_run;
+        a.colmax[o] = best_v;
+        a.argx[o] = best_x;
+    }
+}
+
+// One workgroup per sample: Sa, Sb, the sample's loss, logging means, arg-max label.
+// sample_scal[n] = {Sa, Sb, loss_n, mean positive score, mean negative score, label at arg-max, 0, 0}
+__global__ __launch_bounds__(256) void dense_finalize_kernel(DenseArgs a, float* __restrict__ sample_scal) {
+    __shared__ float red[6][4];
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    const int n = blockIdx.x, P = a.P, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    float sa = 0.f, sb = 0.f, t_lse = 0.f, t_a = 0.f, t_pos = 0.f, t_all = 0.f, best = -INFINITY;
+    int64_t best_flat = 0;
+    for (int y = tid; y < P; y += 256) {
+        const int64_t o = (int64_t)n * P + y;
+        const float mb = a.mask_b[o];
+        sa += a.mask_a[o];
+        sb += mb;
+        t_lse += mb * a.lse[o];
+        t_a += mb * a.colsum_a[o];
+        t_pos += mb * a.possum[o];
+        t_all += a.allsum[o];
+        const float v = a.colmax[o];
+        const int64_t flat = (int64_t)a.argx[o] * P + y;
+        if (v > best || (v == best && flat < best_flat)) { best = v; best_flat = flat; }
+    }
+    float vals[6] = {sa, sb, t_lse, t_a, t_pos, t_all};
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const float s = wave_sum(vals[j]);
+        if (lane == 0) red[j][w] = s;
+    }
+    // arg-max across the wave, then across waves (ties -> smallest flat index, as torch.argmax)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const int64_t of = __shfl_xor(best_flat, off, 64);
+        if (ov > best || (ov == best && of < best_flat)) { best = ov; best_flat = of; }
+    }
+    if (lane == 0) { bv[w] = best; bi[w] = (int)best_flat; }
+    __syncthreads();
+    if (tid == 0) {
+        float t[6];
+        for (int j = 0; j < 6; ++j) t[j] = red[j][0] + red[j][1] + red[j][2] + red[j][3];
+        float bb = bv[0];
+        int bf = bi[0];
+        for (int j = 1; j < 4; ++j)
+            if (bv[j] > bb || (bv[j] == bb && bi[j] < bf)) { bb = bv[j]; bf = bi[j]; }
+        const float Sa = t[0], Sb = t[1], npos = Sa * Sb;
+        float* o = sample_scal + (int64_t)n * 8;
+        o[0] = Sa;
+        o[1] = Sb;
+        o[2] = (Sa * t[2] - t[3]) / npos;                 // 0/0 = NaN when a mask is empty, as the reference
+        o[3] = t[4] / npos;
+        o[4] = (t[5] - t[4]) / ((float)P * (float)P - npos);
+        o[5] = a.mask_a[(int64_t)n * P + bf / P] * a.mask_b[(int64_t)n * P + bf % P];
+        o[6] = 0.f;
+        o[7] = 0.f;
+    }
+}
+
+// out[0] = mean_n scal[n][2] (dense loss), out[1] = 100 * mean_n scal[n][5] (arg-max accuracy)
+__global__ __launch_bounds__(64) void dense_batch_kernel(const float* __restrict__ scal, int B, float* __restrict__ out) {
+    float l = 0.f, c = 0.f;
+    for (int n = threadIdx.x; n < B; n += 64) { l += scal[n * 8 + 2]; c += scal[n * 8 + 5]; }
+    l = wave_sum(l);
+    c = wave_sum(c);
+    if (threadIdx.x == 0) { out[0] = l / (float)B; out[1] = 100.f * c / (float)B; }
+}
+
+// owners = query pixels x (lane), others = key pixels y (LDS tile).
+//   d loss_n / d Ls[x][y] = mb[y] (Sa softmax_x(Ls)[x][y] - ma[x]) / (Sa Sb),  Ls = L w / T
+//   g_dense[c][x] = grad_scale * sum_y kd[c][y] * (w/T) * dLs[x][y]
+template <bool WEIGHTS>
+__global__ __launch_bounds__(256) void dense_bwd_kernel(DenseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    DenseLds& L = *reinterpret_cast<DenseLds*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int n = blockIdx.y, P = a.P;
+    const int x = (blockIdx.x * 4 + wid) * 32 + r;
+    const bool x_ok = x < P;
+    const float* qd = a.qd + (int64_t)n * CH * P;
+    const float* kd = a.kd + (int64_t)n * CH * P;
+    float bq[CH / 2];
+#pragma unroll
+    for (int t = 0; t < CH / 2; ++t) bq[t] = x_ok ? qd[(int64_t)(2 * t + h) * P + x] : 0.f;
+    const float Sa = a.sample_scal[(int64_t)n * 8 + 0], Sb = a.sample_scal[(int64_t)n * 8 + 1];
+    const float gs = a.grad_scale * a.inv_t / (Sa * Sb);
+    const float ma = x_ok ? a.mask_a[(int64_t)n * P + x] : 0.f;
+    int64_t pa = -1, ra = 0;
+    if (WEIGHTS && x_ok) { pa = a.pix_a[(int64_t)n * P + x]; ra = a.reg_a[(int64_t)n * P + x]; }
+    f32x16 U[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) U[cb] = (f32x16){0};
+    for (int y0 = 0; y0 < P; y0 += DKT) {
+        __syncthreads();
+        fill_tile<DKT>(L.T, kd, P, y0, P, tid);
+        if (tid < DKT) {
+            const int y = y0 + tid;
+            L.ma[tid] = y < P ? a.mask_b[(int64_t)n * P + y] : 0.f;   // mb
+            L.aux[tid] = y < P ? a.lse[(int64_t)n * P + y] : 0.f;
+            if (WEIGHTS) {
+                L.pid[tid] = y < P ? a.pix_b[(int64_t)n * P + y] : -2;
+                L.rid[tid] = y < P ? a.reg_b[(int64_t)n * P + y] : 0;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int kk = s * 32;
+            if (y0 + kk >= P) continue;
+            const f32x16 acc = product1<DKP>(L.T, kk, bq, r, h);
+            float p[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int yi = kk + rho(reg, h);
+                const bool valid = (y0 + yi) < P;
+                float w = 1.f;
+                if (WEIGHTS) w = corr_weight(pa, L.pid[yi], ra, L.rid[yi], a.w_pixel, a.w_region, a.w_not);
+                const float ls = acc[reg] * w * a.inv_t;
+                const float sm = __expf(ls - L.aux[yi]);
+                p[reg] = (valid && x_ok) ? gs * w * L.ma[yi] * (Sa * sm - ma) : 0.f;
+            }
+            product2<DKP>(L.T, kk, p, U, r, h);
+        }
+    }
+    if (x_ok) {
+        float* g = a.g_dense + (int64_t)n * CH * P + x;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) g[(int64_t)(cb * 32 + rho(reg, h)) * P] = U[cb][reg];
+    }
+}
+
+static int dense_check(const float* qd, const float* kd, const float* ma, const float* mb, const int64_t* pa,
+                       const int64_t* pb, const int64_t* ra, const int64_t* rb, int B, int C, int P, float t) {
+    if (!qd || !kd || !ma || !mb) return CP2_ERR_NULL;
+    const int nid = (pa != nullptr) + (pb != nullptr) + (ra != nullptr) + (rb != nullptr);
+    if (nid != 0 && nid != 4) return CP2_ERR_NULL;
+    if (B <= 0 || P <= 0 || !(t > 0.f)) return CP2_ERR_SHAPE;
+    if (C != CH) return CP2_ERR_UNSUPPORTED;
+    return CP2_OK;
+}
+
+CP2_API int cp2_dense_infonce_fwd(const float* q_dense, const float* k_dense, const float* mask_a,
+                                  const float* mask_b, const int64_t* pix_a, const int64_t* pix_b,
+                                  const int64_t* reg_a, const int64_t* reg_b, float w_pixel, float w_region,
+                                  float w_not, float temperature, float* lse, float* colsum_a, float* possum,
+                                  float* allsum, float* colmax, int32_t* argx, float* sample_scal, float* batch_out,
+                                  int B, int C, int P, void* stream) {
+    int rc = dense_check(q_dense, k_dense, mask_a, mask_b, pix_a, pix_b, reg_a, reg_b, B, C, P, temperature);
+    if (rc) return rc;
+    if (!lse || !colsum_a || !possum || !allsum || !colmax || !argx || !sample_scal || !batch_out) return CP2_ERR_NULL;
+    DenseArgs a{q_dense, k_dense, mask_a, mask_b, pix_a, pix_b, reg_a, reg_b, w_pixel, w_region, w_not,
+                1.0f / temperature, P, lse, colsum_a, possum, allsum, colmax, argx, nullptr, 0.f, nullptr};
+    const dim3 grid(cp2_cdiv(P, 128), B);
+    const size_t lds = sizeof(DenseLds);
+    if (pix_a) hipLaunchKernelGGL(dense_fwd_kernel<true>, grid, dim3(256), lds, cp2_stream(stream), a);
+    else hipLaunchKernelGGL(dense_fwd_kernel<false>, grid, dim3(256), lds, cp2_stream(stream), a);
+    rc = cp2_launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(dense_finalize_kernel, dim3(B), dim3(256), 0, cp2_stream(stream), a, sample_scal);
+    rc = cp2_launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(dense_batch_kernel, dim3(1), dim3(64), 0, cp2_stream(stream), sample_scal, B, batch_out);
+    return cp2_launch_status();
+}
+
+CP2_API int cp2_dense_infonce_bwd(const float* q_dense, const float* k_dense, const float* mask_a,
+                                  const float* mask_b, const int64_t* pix_a, const int64_t* pix_b,
+                                  const int64_t* reg_a, const int64_t* reg_b, float w_pixel, float w_region,
+                                  float w_not, float temperature, const float* lse, const float* sample_scal,
+                                  float grad_scale, float* g_dense, int B, int C, int P, void* stream) {
+    int rc = dense_check(q_dense, k_dense, mask_a, mask_b, pix_a, pix_b, reg_a, reg_b, B, C, P, temperature);
+    if (rc) return rc;
+    if (!lse || !sample_scal || !g_dense) return CP2_ERR_NULL;
+    DenseArgs a{q_dense, k_dense, mask_a, mask_b, pix_a, pix_b, reg_a, reg_b, w_pixel, w_region, w_not,
+                1.0f / temperature, P, const_cast<float*>(lse), nullptr, nullptr, nullptr, nullptr, nullptr,
+                sample_scal, grad_scale, g_dense};
+    const dim3 grid(cp2_cdiv(P, 128), B);
+    const size_t lds = sizeof(DenseLds);
+    if (pix_a) hipLaunchKernelGGL(dense_bwd_kernel<true>, grid, dim3(256), lds, cp2_stream(stream), a);
+    else hipLaunchKernelGGL(dense_bwd_kernel<false>, grid, dim3(256), lds, cp2_stream(stream), a);
+    return cp2_launch_status();
+}

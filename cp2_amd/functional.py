@@ -1,0 +1,88 @@
+"""Autograd front end of the fused CP2 loss section.
+
+`cp2_loss_section` is everything reference `MODEL.forward_cp2` computes between the
+two encoder calls and the returned loss (builder.py:1261-1268, 1279-1292, 1392-1448)
+as nine kernel launches with no host synchronisation.  The gradient with respect to
+the query feature map is produced inside the forward pass (the queue and the P x P
+logits are each visited once more at most), so `backward` is a single scale.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import ops
+
+
+@dataclass
+class CP2LossOutputs:
+    loss: torch.Tensor               # scalar, differentiable w.r.t. q_feat
+    loss_instance: torch.Tensor      # scalars below are detached
+    loss_dense: torch.Tensor
+    acc_dense: torch.Tensor          # builder.py:1442-1448
+    acc1: torch.Tensor               # builder.py:1441 (top-1 / top-5 of the instance logits)
+    acc5: torch.Tensor
+    k_pos: torch.Tensor              # [B,C] keys to enqueue (builder.py:1426)
+    q_pos: torch.Tensor
+    dense_sample: torch.Tensor       # [B,8] Sa, Sb, loss_n, mean +score, mean -score, arg-max label
+    instance_pos: torch.Tensor       # [B] raw positive logit q_pos.k_pos
+    lnegT: Optional[torch.Tensor]    # [K,B] raw queue logits (only when want_lneg)
+
+
+class _CP2LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q_feat, k_feat, mask_a, mask_b, queue, cfg):
+        (temp_global, temp_local, lmbd_dense, include_background, ids, weights, want_lneg) = cfg
+        B = q_feat.shape[0]
+        need_grad = q_feat.requires_grad
+        q_dense, q_inv, q_part = ops.feat_normalize_pool(q_feat, mask_a)
+        k_dense, _, k_part = ops.feat_normalize_pool(k_feat, mask_b)
+        P = q_dense.shape[2]
+        q_pos, q_neg, q_norms, k_pos, k_neg, extras = ops.pool_finalize(q_part, k_part, P)
+        ne = 3 if include_background else 1
+        ext = extras if include_background else extras[:, :1].contiguous()
+        C = q_pos.shape[1]
+        ins = ops.rowkey_infonce(q_pos, (1, C, 0, 1), B, queue, ext, temp_global,
+                                 grad_scale=(1.0 / B) if need_grad else None, want_lneg=want_lneg)
+        den = ops.dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temp_local, ids, weights)
+        loss = ins.loss + den.loss * lmbd_dense
+        if need_grad:
+            g_dense = ops.dense_infonce_bwd(q_dense, k_dense, mask_a, mask_b, temp_local, den, lmbd_dense / B, ids, weights)
+            if ne == 1:
+                dE = torch.zeros((B, 3), dtype=torch.float32, device=q_feat.device)
+                dE[:, :1] = ins.dE
+            else:
+                dE = ins.dE
+            ds_pos, ds_neg = ops.pool_bwd(ins.drows, dE, q_pos, q_neg, k_pos, k_neg, q_norms, include_background)
+            dq = ops.feat_bwd(q_dense, q_inv, mask_a, g_dense, ds_pos, ds_neg, q_feat)
+            ctx.save_for_backward(dq)
+        acc1 = (ins.cnt_gt < 1).float().mean() * 100.0
+        acc5 = (ins.cnt_gt < 5).float().mean() * 100.0
+        outs = (loss, ins.loss, den.loss, den.acc, acc1, acc5, k_pos, q_pos, den.sample_scal, extras[:, 0].contiguous())
+        if want_lneg:
+            outs = outs + (ins.lnegT,)
+        ctx.mark_non_differentiable(*outs[1:])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_loss, *unused):
+        (dq,) = ctx.saved_tensors
+        return dq * g_loss, None, None, None, None, None
+
+
+def cp2_loss_section(q_feat: torch.Tensor, k_feat: torch.Tensor, mask_a: torch.Tensor, mask_b: torch.Tensor,
+                     queue: torch.Tensor, *, temp_global: float = 0.2, temp_local: float = 1.0,
+                     lmbd_dense: float = 0.2, include_background: bool = False, ids=None,
+                     weights: Tuple[float, float, float] = (1.0, 1.0, 1.0), want_lneg: bool = False) -> CP2LossOutputs:
+    """q_feat / k_feat: encoder outputs [B,128,h,w] (NCHW or channels-last, fp32; k already
+    un-shuffled, no grad); mask_a / mask_b: [B,P] down-sampled foreground masks; queue [128,K].
+    ids = (pixel_ids_a, pixel_ids_b, region_ids_a, region_ids_b) int64 [B,P] when the
+    correspondence weights are not all one (reference builder.py:1225-1243)."""
+    if ids is not None and tuple(float(w) for w in weights) == (1.0, 1.0, 1.0):
+        ids = None                                   # all weights one: the predicate is never needed
+    cfg = (float(temp_global), float(temp_local), float(lmbd_dense), bool(include_background), ids,
+           tuple(float(w) for w in weights), bool(want_lneg))
+    outs = _CP2LossFn.apply(q_feat, k_feat.detach(), mask_a, mask_b, queue, cfg)
+    return CP2LossOutputs(*outs[:10], lnegT=outs[10] if want_lneg else None)

@@ -172,3 +172,173 @@ def enqueue(queue: torch.Tensor, keys: torch.Tensor, ptr: torch.Tensor) -> None:
     rc = lib.cp2_enqueue(_dev(queue, "queue", torch.float32), _dev(keys, "keys", torch.float32),
                          _dev(ptr, "queue_ptr", torch.int64), n, C, K, _stream())
     _lib.check(rc, "cp2_enqueue")
+
+
+# ---------------------------------------------------------------- a7
+def _feat_strides(feat: torch.Tensor) -> Tuple[int, int, int, int, int, int]:
+    """(B, C, P, stride_n, stride_c, stride_p) of an encoder output [B,C,h,w] or [B,C,P]
+    whose pixel axes collapse to one stride (true for NCHW-contiguous and channels-last)."""
+    if feat.dim() == 4:
+        B, C, h, w = feat.shape
+        sn, sc, sh, sw = feat.stride()
+        if h > 1 and sh != w * sw:
+            raise ValueError("feature map pixels are not uniformly strided; call .contiguous() first")
+        return B, C, h * w, sn, sc, sw
+    B, C, P = feat.shape
+    sn, sc, sp = feat.stride()
+    return B, C, P, sn, sc, sp
+
+
+def feat_normalize_pool(feat: torch.Tensor, mask: torch.Tensor):
+    """dense [B,C,P], inv_norm [B,P], pool_partial [B,NT,2,C] (reference builder.py:1261-1268)."""
+    lib = _lib.load()
+    if not feat.is_cuda:
+        raise _lib.Cp2LibraryError(f"feat is on {feat.device}; cp2_amd ops run on the GPU only")
+    if feat.dtype != torch.float32:
+        raise TypeError(f"feat: expected float32, got {feat.dtype}")
+    B, C, P, sn, sc, sp = _feat_strides(feat)
+    dense = torch.empty((B, C, P), dtype=torch.float32, device=feat.device)
+    inv_norm = torch.empty((B, P), dtype=torch.float32, device=feat.device)
+    partial = torch.empty((B, (P + 63) // 64, 2, C), dtype=torch.float32, device=feat.device)
+    rc = lib.cp2_feat_normalize_pool(feat.data_ptr(), sn, sc, sp, _dev(mask, "mask", torch.float32), dense.data_ptr(),
+                                     inv_norm.data_ptr(), partial.data_ptr(), B, C, P, _stream())
+    _lib.check(rc, "cp2_feat_normalize_pool")
+    return dense, inv_norm, partial
+
+
+def pool_finalize(q_partial: torch.Tensor, k_partial: torch.Tensor, P: int):
+    lib = _lib.load()
+    B, _, _, C = q_partial.shape
+    dev = q_partial.device
+    vec = lambda: torch.empty((B, C), dtype=torch.float32, device=dev)  # noqa: E731
+    q_pos, q_neg, k_pos, k_neg = vec(), vec(), vec(), vec()
+    q_norms = torch.empty((B, 2), dtype=torch.float32, device=dev)
+    extras = torch.empty((B, 3), dtype=torch.float32, device=dev)
+    rc = lib.cp2_pool_finalize(_dev(q_partial, "q_partial"), _dev(k_partial, "k_partial"), q_pos.data_ptr(),
+                               q_neg.data_ptr(), q_norms.data_ptr(), k_pos.data_ptr(), k_neg.data_ptr(),
+                               extras.data_ptr(), B, C, P, _stream())
+    _lib.check(rc, "cp2_pool_finalize")
+    return q_pos, q_neg, q_norms, k_pos, k_neg, extras
+
+
+def pool_bwd(drow_pos, dE, q_pos, q_neg, k_pos, k_neg, q_norms, include_background: bool):
+    lib = _lib.load()
+    B, C = q_pos.shape
+    ds_pos, ds_neg = torch.empty_like(q_pos), torch.empty_like(q_pos)
+    rc = lib.cp2_pool_bwd(_dev(drow_pos, "drow_pos"), _dev(dE, "dE"), _dev(q_pos, "q_pos"), _dev(q_neg, "q_neg"),
+                          _dev(k_pos, "k_pos"), _dev(k_neg, "k_neg"), _dev(q_norms, "q_norms"), int(include_background),
+                          ds_pos.data_ptr(), ds_neg.data_ptr(), B, C, _stream())
+    _lib.check(rc, "cp2_pool_bwd")
+    return ds_pos, ds_neg
+
+
+def feat_bwd(dense, inv_norm, mask, g_dense, ds_pos, ds_neg, like: torch.Tensor) -> torch.Tensor:
+    """d loss / d feat, laid out like `like` (the encoder output)."""
+    lib = _lib.load()
+    dfeat = torch.empty_like(like)           # preserves NCHW / channels-last strides
+    B, C, P, sn, sc, sp = _feat_strides(dfeat)
+    rc = lib.cp2_feat_bwd(_dev(dense, "dense"), _dev(inv_norm, "inv_norm"), _dev(mask, "mask"), _dev(g_dense, "g_dense"),
+                          _dev(ds_pos, "ds_pos"), _dev(ds_neg, "ds_neg"), dfeat.data_ptr(), sn, sc, sp, B, C, P, _stream())
+    _lib.check(rc, "cp2_feat_bwd")
+    return dfeat
+
+
+# ---------------------------------------------------------------- a10 / a16
+class RowKeyResult:
+    __slots__ = ("loss", "lse", "loss_rows", "cnt_gt", "drows", "dE", "lnegT")
+
+
+def rowkey_infonce(rows: torch.Tensor, row_layout: Tuple[int, int, int, int], R: int, keys: torch.Tensor,
+                   extras: torch.Tensor, temperature: float, grad_scale: Optional[float],
+                   drows_like: Optional[torch.Tensor] = None, want_lneg: bool = False) -> RowKeyResult:
+    """InfoNCE of R row vectors against the queue `keys` [C,K] with `extras` [R,NE] prepended
+    (column 0 = positive).  row_layout = (RP, stride_n, stride_x, stride_c): element (c, r) of
+    `rows` lives at (r//RP)*stride_n + (r%RP)*stride_x + c*stride_c.
+    grad_scale None -> forward only; else drows (same layout, allocated like `drows_like` or
+    `rows`) and dE carry grad_scale * d(sum_r loss_r)/d(rows, extras)."""
+    lib = _lib.load()
+    C, K = keys.shape
+    RP, sn, sx, sc = row_layout
+    NE = extras.shape[1]
+    dev = keys.device
+    ns = lib.cp2_rowkey_num_splits(R, K)
+    _lib.check(min(ns, 0), "cp2_rowkey_num_splits")
+    part_m = torch.empty((ns, R), dtype=torch.float32, device=dev)
+    part_s = torch.empty((ns, R), dtype=torch.float32, device=dev)
+    part_cnt = torch.empty((ns, R), dtype=torch.int32, device=dev)
+    want_grad = grad_scale is not None
+    part_U = torch.empty((ns, C, R), dtype=torch.float32, device=dev) if want_grad else None
+    out = RowKeyResult()
+    out.lnegT = torch.empty((K, R), dtype=torch.float32, device=dev) if want_lneg else None
+    if not rows.is_cuda or rows.dtype != torch.float32:
+        raise _lib.Cp2LibraryError("rowkey_infonce: rows must be a float32 GPU tensor")
+    rc = lib.cp2_rowkey_infonce_fwd(rows.data_ptr(), RP, sn, sx, sc, R, _dev(keys, "keys", torch.float32), K,
+                                    _dev(extras, "extras", torch.float32), NE, float(temperature), ns,
+                                    part_m.data_ptr(), part_s.data_ptr(), part_cnt.data_ptr(), _opt(part_U, "part_U"),
+                                    _opt(out.lnegT, "lnegT"), C, _stream())
+    _lib.check(rc, "cp2_rowkey_infonce_fwd")
+    out.lse = torch.empty(R, dtype=torch.float32, device=dev)
+    out.loss_rows = torch.empty(R, dtype=torch.float32, device=dev)
+    out.cnt_gt = torch.empty(R, dtype=torch.int32, device=dev)
+    out.loss = torch.empty((), dtype=torch.float32, device=dev)
+    out.drows = out.dE = None
+    if want_grad:
+        out.drows = torch.empty_like(rows if drows_like is None else drows_like)
+        out.dE = torch.empty((R, NE), dtype=torch.float32, device=dev)
+    rc = lib.cp2_rowkey_infonce_finalize(part_m.data_ptr(), part_s.data_ptr(), part_cnt.data_ptr(), _opt(part_U, "part_U"),
+                                         ns, extras.data_ptr(), NE, float(temperature),
+                                         float(grad_scale if want_grad else 0.0), R, RP, sn, sx, sc, out.lse.data_ptr(),
+                                         out.loss_rows.data_ptr(), out.cnt_gt.data_ptr(), _opt(out.drows, "drows"),
+                                         _opt(out.dE, "dE"), out.loss.data_ptr(), C, _stream())
+    _lib.check(rc, "cp2_rowkey_infonce_finalize")
+    return out
+
+
+# ---------------------------------------------------------------- a8 / a9
+class DenseResult:
+    __slots__ = ("loss", "acc", "lse", "sample_scal", "colmax", "argx")
+
+
+def _ids4(ids):
+    if ids is None:
+        return None, None, None, None
+    pa, pb, ra, rb = ids
+    return (_dev(pa, "pixel_ids_a", torch.int64), _dev(pb, "pixel_ids_b", torch.int64),
+            _dev(ra, "region_ids_a", torch.int64), _dev(rb, "region_ids_b", torch.int64))
+
+
+def dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temperature: float, ids=None,
+                      weights=(1.0, 1.0, 1.0)) -> DenseResult:
+    lib = _lib.load()
+    B, C, P = q_dense.shape
+    dev = q_dense.device
+    f = lambda: torch.empty((B, P), dtype=torch.float32, device=dev)  # noqa: E731
+    res = DenseResult()
+    res.lse, colsum, possum, allsum, res.colmax = f(), f(), f(), f(), f()
+    res.argx = torch.empty((B, P), dtype=torch.int32, device=dev)
+    res.sample_scal = torch.empty((B, 8), dtype=torch.float32, device=dev)
+    batch = torch.empty(2, dtype=torch.float32, device=dev)
+    pa, pb, ra, rb = _ids4(ids)
+    rc = lib.cp2_dense_infonce_fwd(_dev(q_dense, "q_dense", torch.float32), _dev(k_dense, "k_dense", torch.float32),
+                                   _dev(mask_a, "mask_a", torch.float32), _dev(mask_b, "mask_b", torch.float32),
+                                   pa, pb, ra, rb, float(weights[0]), float(weights[1]), float(weights[2]),
+                                   float(temperature), res.lse.data_ptr(), colsum.data_ptr(), possum.data_ptr(),
+                                   allsum.data_ptr(), res.colmax.data_ptr(), res.argx.data_ptr(),
+                                   res.sample_scal.data_ptr(), batch.data_ptr(), B, C, P, _stream())
+    _lib.check(rc, "cp2_dense_infonce_fwd")
+    res.loss, res.acc = batch[0], batch[1]
+    return res
+
+
+def dense_infonce_bwd(q_dense, k_dense, mask_a, mask_b, temperature: float, fwd: DenseResult, grad_scale: float,
+                      ids=None, weights=(1.0, 1.0, 1.0)) -> torch.Tensor:
+    lib = _lib.load()
+    B, C, P = q_dense.shape
+    g = torch.empty_like(q_dense)
+    pa, pb, ra, rb = _ids4(ids)
+    rc = lib.cp2_dense_infonce_bwd(_dev(q_dense, "q_dense"), _dev(k_dense, "k_dense"), _dev(mask_a, "mask_a"),
+                                   _dev(mask_b, "mask_b"), pa, pb, ra, rb, float(weights[0]), float(weights[1]),
+                                   float(weights[2]), float(temperature), fwd.lse.data_ptr(), fwd.sample_scal.data_ptr(),
+                                   float(grad_scale), g.data_ptr(), B, C, P, _stream())
+    _lib.check(rc, "cp2_dense_infonce_bwd")
+    return g

@@ -84,6 +84,71 @@ int cp2_ema_multi(float* const* k_ptrs, const float* const* q_ptrs, const int32_
  * The pointer is read and advanced on the device: no host synchronisation.  n <= K. */
 int cp2_enqueue(float* queue, const float* keys, int64_t* ptr, int n, int C, int K, void* stream);
 
+/* ---- a7: per-pixel L2 normalise + masked pooling ---------- builder.py:1261-1268,1279-1285
+ * feat: encoder output addressed as feat[n*stride_n + c*stride_c + x*stride_p] (NCHW or channels-last),
+ * mask: [B,P] 0/1.  dense[B,C,P] = feat / max(|feat[:,x]|, 1e-12); inv_norm[B,P];
+ * pool_partial: workspace [B, ceil(P/64), 2, C] of per-tile masked / un-masked channel sums.  C must be 128. */
+int cp2_feat_normalize_pool(const float* feat, int64_t stride_n, int64_t stride_c, int64_t stride_p,
+                            const float* mask, float* dense, float* inv_norm, float* pool_partial,
+                            int B, int C, int P, void* stream);
+/* Reduce the tile sums of the query and key maps to the pooled unit vectors
+ * q_pos,q_neg,k_pos,k_neg [B,C], the query pool norms q_norms [B,2], and the raw extra logits
+ * extras[B,3] = {q_pos.k_pos, q_pos.q_neg, q_pos.k_neg}      (builder.py:1264-1268,1281-1285,1395,1416-1417) */
+int cp2_pool_finalize(const float* q_partial, const float* k_partial, float* q_pos, float* q_neg,
+                      float* q_norms, float* k_pos, float* k_neg, float* extras, int B, int C, int P, void* stream);
+/* Backward of the pooled query vectors: drow_pos [B,C] = d loss/d q_pos through the queue logits,
+ * dE [B,3] = d loss/d extras  ->  ds_pos, ds_neg [B,C] = d loss / d (masked / un-masked channel sums). */
+int cp2_pool_bwd(const float* drow_pos, const float* dE, const float* q_pos, const float* q_neg,
+                 const float* k_pos, const float* k_neg, const float* q_norms, int include_background,
+                 float* ds_pos, float* ds_neg, int B, int C, void* stream);
+/* Backward of the normalisation with the pooled gradients folded in; dfeat uses the strides of feat. */
+int cp2_feat_bwd(const float* dense, const float* inv_norm, const float* mask, const float* g_dense,
+                 const float* ds_pos, const float* ds_neg, float* dfeat, int64_t stride_n, int64_t stride_c,
+                 int64_t stride_p, int B, int C, int P, void* stream);
+
+/* ---- a10 / a16: rows-vs-queue InfoNCE (f32 MFMA) ---------- builder.py:1395-1428 (instance),
+ *                                                            :866-873,906-908,150-176 (DenseCL local)
+ * logits of row r = [extras[r,:NE] | rows[r].keys[:,j], j<K] / T, target = extras column 0;
+ * loss = mean_r (logsumexp_r - extras[r,0]/T).  The queue is read once: the forward pass also
+ * accumulates sum_j softmax_j * keys[:,j], so the gradient needs no second pass over the queue.
+ * rows: element (c, r) at (r/RP)*r_sn + (r%RP)*r_sx + c*r_sc;  keys: [C,K] (column = key);  C = 128.
+ * nsplit = cp2_rowkey_num_splits(R,K) key ranges run in parallel; workspaces part_m, part_s [nsplit,R],
+ * part_cnt [nsplit,R] int32, part_U [nsplit,C,R] (NULL: no gradient), lnegT [K,R] raw logits or NULL. */
+int cp2_rowkey_num_splits(int R, int K);
+int cp2_rowkey_infonce_fwd(const float* rows, int RP, int64_t r_sn, int64_t r_sx, int64_t r_sc, int R,
+                           const float* keys, int K, const float* extras, int NE, float temperature,
+                           int nsplit, float* part_m, float* part_s, int32_t* part_cnt, float* part_U,
+                           float* lnegT, int C, void* stream);
+/* Merge the splits: lse[R], loss_rows[R], cnt_gt[R] (# negatives whose logit exceeds the positive),
+ * drows (same addressing as rows, with d_* strides; NULL: skip) = grad_scale * d sum_r loss_r / d rows,
+ * dE [R,NE] likewise (may be NULL), loss_mean[1] = mean_r loss_r (may be NULL). */
+int cp2_rowkey_infonce_finalize(const float* part_m, const float* part_s, const int32_t* part_cnt,
+                                const float* part_U, int nsplit, const float* extras, int NE,
+                                float temperature, float grad_scale, int R, int RP, int64_t d_sn,
+                                int64_t d_sx, int64_t d_sc, float* lse, float* loss_rows, int32_t* cnt_gt,
+                                float* drows, float* dE, float* loss_mean, int C, void* stream);
+
+/* ---- a8 / a9 (+a6, part of a15): dense pixel-to-pixel InfoNCE (f32 MFMA) -- builder.py:1289-1292,
+ *                                                 1225-1243 (weights), 1392, 1431-1437, 1442-1448
+ * L[n,x,y] = q_dense[n,:,x].k_dense[n,:,y] * w[n,x,y] / T;  -log_softmax over the QUERY axis x;
+ * loss_n = sum_{x,y} nll[x,y] mask_a[x] mask_b[y] / sum mask_a[x] mask_b[y].  The P x P logits are never
+ * written to memory.  pix_*, reg_* (all four or none): int64 [B,P] ids for the correspondence weights
+ * (pixel match -> w_pixel, else known-region match -> w_region, else w_not); NULL = all weights 1.
+ * Per key pixel outputs [B,P]: lse, colsum_a, possum, allsum, colmax, argx (workspaces kept for backward /
+ * logging).  sample_scal [B,8] = {Sa, Sb, loss_n, mean positive score, mean negative score, label at the
+ * arg-max pair, 0, 0};  batch_out[2] = {mean_n loss_n, 100 * mean_n label}.   C = 128. */
+int cp2_dense_infonce_fwd(const float* q_dense, const float* k_dense, const float* mask_a, const float* mask_b,
+                          const int64_t* pix_a, const int64_t* pix_b, const int64_t* reg_a, const int64_t* reg_b,
+                          float w_pixel, float w_region, float w_not, float temperature, float* lse,
+                          float* colsum_a, float* possum, float* allsum, float* colmax, int32_t* argx,
+                          float* sample_scal, float* batch_out, int B, int C, int P, void* stream);
+/* g_dense [B,C,P] = grad_scale * d (sum_n loss_n) / d q_dense, recomputing the logits tile by tile. */
+int cp2_dense_infonce_bwd(const float* q_dense, const float* k_dense, const float* mask_a, const float* mask_b,
+                          const int64_t* pix_a, const int64_t* pix_b, const int64_t* reg_a, const int64_t* reg_b,
+                          float w_pixel, float w_region, float w_not, float temperature, const float* lse,
+                          const float* sample_scal, float grad_scale, float* g_dense, int B, int C, int P,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

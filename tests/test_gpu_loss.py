@@ -1,0 +1,200 @@
+"""GPU: the fp32 MFMA loss kernels through the C ABI against the CPU oracle and the
+golden vectors recorded from the reference.
+
+Tolerances (stated per north_star: fp32 logits within 1e-4 of the reference):
+  raw logits / unit vectors      |err| <= 2e-6   (f32 MFMA = exact fp32 fma chain)
+  losses (scalars, O(1..10))     |err| <= 2e-5
+  gradient d loss / d q_feat     max|err| <= 2e-5 * max|grad| + 1e-9
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cp2_amd import functional as CF
+from cp2_amd import ops
+from oracle import cp2_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+CP2_CASES = ["cp2_b4_64_k64", "cp2_b4_96_k64_wrap_bg", "cp2_b3_80x112_k1024", "cp2_proposed_weights"]
+
+
+def load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name + ".npz")))
+
+
+def G(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def assert_close(got, want, atol, rtol=0.0, what=""):
+    got = torch.as_tensor(got).detach().double().cpu()
+    want = torch.as_tensor(want).detach().double().cpu()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    err = (got - want).abs().max().item() if got.numel() else 0.0
+    lim = atol + rtol * want.abs().max().item()
+    assert err <= lim, f"{what}: max err {err:.3e} > {lim:.3e}"
+
+
+def grad_close(got, want, what="grad"):
+    assert_close(got, want, 1e-9, 2e-5, what)
+
+
+@pytest.mark.parametrize("name", CP2_CASES)
+def test_loss_section_golden(golden_dir, name):
+    g = load(golden_dir, name)
+    b, h, w, K, stride, inc_bg = [int(v) for v in g["cfg"]]
+    tg, tl, lmbd, wp, wr, wn, _ = [float(v) for v in g["cfg_f"]]
+    q = G(g["q_feat"]).requires_grad_(True)
+    ids = None
+    if name == "cp2_proposed_weights":
+        ids = tuple(G(g[k]).reshape(b, -1) for k in ("pixel_ids_a", "pixel_ids_b", "region_ids_a", "region_ids_b"))
+    out = CF.cp2_loss_section(q, G(g["k_feat"]), G(g["mask_a"]), G(g["mask_b"]), G(g["queue_before"]),
+                              temp_global=tg, temp_local=tl, lmbd_dense=lmbd, include_background=bool(inc_bg),
+                              ids=ids, weights=(wp, wr, wn), want_lneg=True)
+    out.loss.backward()
+    assert_close(out.q_pos, g["q_pos"], 2e-6, what="q_pos")
+    assert_close(out.k_pos, g["k_pos"], 2e-6, what="k_pos")
+    assert_close(out.instance_pos, g["l_pos"][:, 0], 2e-6, what="l_pos")
+    assert_close(out.lnegT.t(), g["l_neg"], 2e-6, what="l_neg")
+    assert_close(out.loss_instance, g["loss_instance"], 2e-5, what="loss_instance")
+    assert_close(out.loss_dense, g["loss_dense"], 2e-5, what="loss_dense")
+    assert_close(out.loss, g["loss"], 2e-5, what="loss")
+    grad_close(q.grad, g["dq_feat"], "dq_feat")
+    assert_close(out.acc_dense, g["acc_dense"], 1e-4, what="acc_dense")
+    assert_close(out.acc1, g["acc1"], 1e-4, what="acc1")
+    assert_close(out.acc5, g["acc5"], 1e-4, what="acc5")
+    assert_close(out.dense_sample[:, 3], g["dense_positive_average"], 2e-6, what="dense +mean")
+    assert_close(out.dense_sample[:, 4], g["dense_negative_average"], 2e-6, what="dense -mean")
+
+
+def test_feat_kernels_vs_oracle_and_channels_last():
+    gen = torch.Generator().manual_seed(0)
+    B, C, h, w = 5, 128, 9, 13
+    feat = torch.randn(B, C, h, w, generator=gen)
+    feat[1, :, 2, 3] = 0.0                              # a zero vector: clamp path of F.normalize
+    mask = (torch.rand(B, h * w, generator=gen) > 0.4).float()
+    mask[2] = 0.0                                       # empty foreground -> pooled vector is zero
+    d_ref, pos_ref, neg_ref = O.normalize_and_pool(feat, mask)
+    for fmt in (torch.contiguous_format, torch.channels_last):
+        fd = feat.to(DEV).contiguous(memory_format=fmt)
+        dense, inv, part = ops.feat_normalize_pool(fd, mask.to(DEV))
+        assert_close(dense, d_ref, 1e-6, what="dense")
+        q_pos, q_neg, q_norms, k_pos, k_neg, extras = ops.pool_finalize(part, part, h * w)
+        assert_close(q_pos, pos_ref, 2e-6, what="pos")
+        assert_close(q_neg, neg_ref, 2e-6, what="neg")
+        assert_close(k_pos, pos_ref, 2e-6, what="kpos")
+        assert_close(extras[:, 1], (pos_ref * neg_ref).sum(1), 3e-6, what="extras")
+
+
+def _rand_case(B, hw, K, seed, stride_fmt=torch.contiguous_format):
+    gen = torch.Generator().manual_seed(seed)
+    h, w = hw
+    q = torch.randn(B, 128, h, w, generator=gen)
+    k = torch.randn(B, 128, h, w, generator=gen)
+    ma = (torch.rand(B, h * w, generator=gen) > 0.45).float()
+    mb = (torch.rand(B, h * w, generator=gen) > 0.55).float()
+    queue = torch.nn.functional.normalize(torch.randn(128, K, generator=gen), dim=0)
+    return q, k, ma, mb, queue
+
+
+def _oracle_loss(q, k, ma, mb, queue, tg, tl, lmbd, inc_bg):
+    q = q.clone().requires_grad_(True)
+    qd, qp, qn = O.normalize_and_pool(q, ma)
+    with torch.no_grad():
+        kd, kp, kn = O.normalize_and_pool(k, mb)
+    li, logits, _, _ = O.instance_infonce(qp, kp, queue, tg, qn, kn, inc_bg)
+    ld, per_sample, _ = O.dense_infonce(O.dense_logits(qd, kd), ma, mb, tl)
+    loss = li + lmbd * ld
+    loss.backward()
+    return loss.detach(), li.detach(), ld.detach(), q.grad, per_sample.detach()
+
+
+@pytest.mark.parametrize("B,hw,K,inc_bg,fmt", [
+    (32, (14, 14), 65536, False, torch.channels_last),     # BASELINE config 2 shapes
+    (3, (5, 7), 300, True, torch.contiguous_format),       # ragged everything, K not a tile multiple
+    (40, (2, 2), 1000, False, torch.contiguous_format),    # 2 row tiles in the instance kernel
+    (70, (3, 3), 4096, True, torch.contiguous_format),     # > 64 rows
+    (2, (32, 32), 2048, False, torch.channels_last),       # P = 1024 (config 4 at OS16)
+    (1, (12, 11), 64, False, torch.contiguous_format),     # P = 132: partial 32-tile and partial 64-tile
+])
+def test_loss_section_random_vs_oracle(B, hw, K, inc_bg, fmt):
+    q, k, ma, mb, queue = _rand_case(B, hw, K, seed=B * 1000 + K)
+    tg, tl, lmbd = 0.2, 0.7, 0.35
+    loss, li, ld, dq, per_sample = _oracle_loss(q, k, ma, mb, queue, tg, tl, lmbd, inc_bg)
+    qg = q.to(DEV).contiguous(memory_format=fmt).requires_grad_(True)
+    out = CF.cp2_loss_section(qg, k.to(DEV).contiguous(memory_format=fmt), ma.to(DEV), mb.to(DEV), queue.to(DEV),
+                              temp_global=tg, temp_local=tl, lmbd_dense=lmbd, include_background=inc_bg)
+    (out.loss * 1.5).backward()                              # non-unit upstream gradient
+    assert_close(out.loss_instance, li, 2e-5, what="loss_instance")
+    assert_close(out.loss_dense, ld, 2e-5, what="loss_dense")
+    assert_close(out.dense_sample[:, 2], per_sample, 2e-5, what="loss_dense per sample")
+    assert_close(out.loss, loss, 2e-5, what="loss")
+    grad_close(qg.grad, dq * 1.5, "dq_feat")
+    assert qg.grad.stride() == qg.stride()
+
+
+def test_empty_mask_gives_nan_like_reference():
+    q, k, ma, mb, queue = _rand_case(2, (4, 4), 128, seed=9)
+    mb[1] = 0.0
+    _, _, ld, _, _ = _oracle_loss(q, k, ma, mb, queue, 0.2, 1.0, 0.2, False)
+    out = CF.cp2_loss_section(q.to(DEV), k.to(DEV), ma.to(DEV), mb.to(DEV), queue.to(DEV))
+    assert torch.isnan(ld) and torch.isnan(out.loss_dense)
+    assert not torch.isnan(out.dense_sample[0, 2])
+
+
+@pytest.mark.parametrize("name", ["densecl_b2_128_k64", "densecl_b2_96_k64_coord"])
+def test_rowkey_densecl_golden(golden_dir, name):
+    """T19: per-pixel rows against queue2 (reference builder.py:866-873,906-908)."""
+    g = load(golden_dir, name)
+    tl = float(g["cfg_f"][1])
+    ql = torch.from_numpy(g["q_local"]).clone().requires_grad_(True)          # [b, C, S2]
+    pos = torch.from_numpy(g["pos_local"]).reshape(-1).clone().requires_grad_(True)
+    b, C, S2 = ql.shape
+    loss_ref = O.queue_infonce(ql.permute(0, 2, 1).reshape(-1, C), pos, torch.from_numpy(g["queue2_before"]), tl)
+    loss_ref.backward()
+    assert_close(loss_ref, g["loss_local"], 2e-6)
+    qd = ql.detach().to(DEV)
+    R = b * S2
+    res = ops.rowkey_infonce(qd, (S2, C * S2, 1, S2), R, G(g["queue2_before"]), pos.detach().reshape(-1, 1).to(DEV),
+                             tl, grad_scale=1.0 / R, want_lneg=True)
+    assert_close(res.lnegT.t(), g["neg_local"], 2e-6, what="neg_local")
+    assert_close(res.loss, g["loss_local"], 2e-5, what="loss_local")
+    grad_close(res.drows, ql.grad, "d q_local")
+    grad_close(res.dE[:, 0], pos.grad, "d pos")
+
+
+def test_rowkey_large_split_property():
+    """BASELINE config-5 shape (6272 rows x 65536 keys) is too big for the CPU oracle in a
+    unit test: check it through size-independent properties instead --
+    (1) a 640-row x 8192-key slice against the oracle, (2) logsumexp over the whole queue
+    equals logaddexp of the two half queues, (3) permuting keys leaves loss and grads unchanged."""
+    gen = torch.Generator().manual_seed(3)
+    b, C, S2, K = 32, 128, 196, 65536
+    rows = torch.nn.functional.normalize(torch.randn(b, C, S2, generator=gen), dim=1).to(DEV)
+    queue = torch.nn.functional.normalize(torch.randn(C, K, generator=gen), dim=0).to(DEV)
+    pos = (torch.rand(b * S2, 1, generator=gen) * 2 - 1).to(DEV)
+    R, lay, T = b * S2, (S2, C * S2, 1, S2), 0.2
+    full = ops.rowkey_infonce(rows, lay, R, queue, pos, T, grad_scale=1.0 / R)
+    none = torch.full_like(pos, -1e30)                          # an extra logit that contributes exp(-inf) = 0
+    h1 = ops.rowkey_infonce(rows, lay, R, queue[:, :K // 2].contiguous(), none, T, None)
+    h2 = ops.rowkey_infonce(rows, lay, R, queue[:, K // 2:].contiguous(), pos, T, None)
+    assert_close(torch.logaddexp(h1.lse, h2.lse), full.lse, 2e-5, what="lse split")
+    perm = torch.randperm(K, generator=gen).to(DEV)
+    pq = ops.rowkey_infonce(rows, lay, R, queue[:, perm].contiguous(), pos, T, grad_scale=1.0 / R)
+    assert_close(pq.loss, full.loss, 2e-5, what="loss under key permutation")
+    grad_close(pq.drows, full.drows, "grad under key permutation")
+    # slice against the oracle
+    rs, ks = 640, 8192
+    sub_rows = rows.reshape(b, C, S2)[:4].contiguous()           # 4 samples = 784 rows; use the first 640
+    r_cpu = sub_rows.cpu().permute(0, 2, 1).reshape(-1, C)[:rs].clone().requires_grad_(True)
+    p_cpu = pos[:rs, 0].cpu().clone().requires_grad_(True)
+    want = O.queue_infonce(r_cpu, p_cpu, queue[:, :ks].cpu(), T)
+    want.backward()
+    got = ops.rowkey_infonce(sub_rows, lay, rs, queue[:, :ks].contiguous(), pos[:rs].contiguous(), T, grad_scale=1.0 / rs)
+    assert_close(got.loss, want.detach(), 2e-5, what="slice loss")
+    got_rows = got.drows.permute(0, 2, 1).reshape(-1, C)[:rs]
+    grad_close(got_rows, r_cpu.grad, "slice d rows")
+    grad_close(got.dE[:, 0], p_cpu.grad, "slice d pos")
