@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256) void rowkey_finalize_kernel(RowKeyFinArgs a) {
         cnt += a.part_cnt[(int64_t)s * a.R + row];
     }
     for (int j = 0; j < a.NE; ++j) Z += expf(e[j] - M);
+    for (int j = 1; j < a.NE; ++j) cnt += (e[j] > e[0]) ? 1 : 0;  // extra negatives also rank against the positive
     const float lse = M + logf(Z);
     if (w == 0) {
         a.lse[row] = lse;

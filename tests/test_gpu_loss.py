@@ -33,6 +33,8 @@ def assert_close(got, want, atol, rtol=0.0, what=""):
     got = torch.as_tensor(got).detach().double().cpu()
     want = torch.as_tensor(want).detach().double().cpu()
     assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert torch.equal(torch.isnan(got), torch.isnan(want)), f"{what}: NaN pattern differs"
+    got, want = torch.nan_to_num(got, nan=0.0), torch.nan_to_num(want, nan=0.0)
     err = (got - want).abs().max().item() if got.numel() else 0.0
     lim = atol + rtol * want.abs().max().item()
     assert err <= lim, f"{what}: max err {err:.3e} > {lim:.3e}"
