@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark: CP2 pre-training images/sec (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 30 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one full optimisation step of the CP2 hot path on one batch of synthetic copy-paste
+pairs: composition, both encoders (PyTorch-ROCm, bf16 autocast), EMA, shuffle-BN, fused dense +
+instance InfoNCE (hand-written gfx950 kernels, fp32), backward, SGD update, enqueue.  Workload at
+N=1 = BASELINE.json configs[1]: ResNet-50 + FCN(contrast) head at output stride 16, 224x224,
+queue 65536, 32 images per GPU (weak scaling: 32 per GPU at every N).  Prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+BF16_DENSE_PEAK_TFLOPS = 2500.0
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=30)
+    p.add_argument("--warmup", type=int, default=10)
+    p.add_argument("--batch-per-gpu", type=int, default=32)
+    p.add_argument("--img", type=int, default=224)
+    p.add_argument("--queue", type=int, default=65536)
+    p.add_argument("--config", default=os.path.join(ROOT, "configs", "config_pretrain_r50_fcn.py"))
+    p.add_argument("--amp", default="bf16", choices=["bf16", "none"])
+    p.add_argument("--graph", default="auto", choices=["auto", "on", "off"], help="whole-step hipGraph (auto: on at N=1)")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-batch", type=int, default=8)
+    p.add_argument("--cpu-steps", type=int, default=2)
+    return p.parse_args()
+
+
+def count_flops_per_image(model, batch):
+    """FLOPs of one step (q forward+backward, k forward, loss GEMMs excluded) via torch's flop counter."""
+    from torch.utils.flop_counter import FlopCounterMode
+    with FlopCounterMode(display=False) as fc:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = model.encoder_q(batch["img_a"])
+            with torch.no_grad():
+                model.encoder_k(batch["img_b"])
+        y.float().mean().backward()
+    model.encoder_q.zero_grad(set_to_none=True)
+    return fc.get_total_flops() / batch["img_a"].shape[0]
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from cp2_amd import builder, ops, synthetic
+    from cp2_amd.config import Config
+    from cp2_amd.engine import TrainStep
+    from cp2_amd.main import make_optimizer
+    from cp2_amd.pretrain_types import PretrainType
+
+    torch.manual_seed(0)
+    cfg = Config.fromfile(args.config)
+    amp = torch.bfloat16 if args.amp == "bf16" else None
+    model = builder.MODEL(cfg, rank=rank, K=args.queue, pretrain_from_scratch=True, pretrain_type=PretrainType.CP2,
+                          device=dev, amp_dtype=amp, channels_last=True).to(dev)
+    model.encoder_q.to(memory_format=torch.channels_last)
+    model.encoder_k.to(memory_format=torch.channels_last)
+    model.train()
+    use_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
+    wrapped = model
+    if world > 1:
+        wrapped = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], output_device=local,
+                                                            broadcast_buffers=False, gradient_as_bucket_view=True)
+
+    class A:  # optimizer settings of reference main.py defaults
+        lr, momentum, weight_decay, optim = 0.03, 0.9, 1e-4, "sgd"
+    opt = make_optimizer(list(model.parameters()), A, dev, capturable=use_graph)
+    b, hw = args.batch_per_gpu, args.img
+    batches = [synthetic.make_batch(b, hw, hw, dev, seed=rank * 9973 + i) for i in range(4)]
+    flops_img = count_flops_per_image(model, batches[0])
+    runner = TrainStep(wrapped, opt, use_graph=use_graph, warmup_steps=3)
+
+    # the EMA is hoisted in front of the (graph-captured) rest of the step so each of its launches can be
+    # bracketed by HIP events on the launch stream; it reads theta_q after the previous optimizer step and
+    # runs before the key encoder, exactly where the reference's call does (builder.py:1272).
+    model.ema_in_forward = False
+    ema_events = []
+
+    def one_step(i, timed):
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            model._momentum_update_key_encoder()
+            e1.record()
+            ema_events.append((e0, e1))
+        else:
+            model._momentum_update_key_encoder()
+        return runner(batches[i % len(batches)])
+
+    for i in range(args.warmup + (4 if use_graph else 0)):
+        one_step(i, False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loss = None
+    for i in range(args.steps):
+        loss = one_step(i, True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    loss_val = float(loss)
+    assert loss_val == loss_val, "loss is NaN"
+
+    ema_ms = sum(a.elapsed_time(bb) for a, bb in ema_events) / len(ema_events)
+    n_param_floats = model._flat_q.numel()
+    ema_bytes = 12 * n_param_floats                      # read k, read q, write k: 12 algorithmic bytes per parameter slot
+    achieved = ema_bytes / (ema_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "ema_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    imgs = b * world * args.steps
+    value = imgs / dt
+    out = {
+        "metric": "pretrain images/sec (whole node), ResNet-50 CP2 224^2, queue=65536",
+        "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16" if amp is not None else "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: ResNet-50 + FCN(contrast) head OS16, {hw}x{hw} copy-paste pairs, "
+                               f"queue={args.queue}, {b} img/GPU, encoders bf16 autocast channels-last, loss kernels fp32 (f32 MFMA), "
+                               f"SGD(0.9, wd 1e-4), random-init weights",
+                   "global_batch": b * world, "parallelism": f"dp{world}", "hipgraph": bool(use_graph),
+                   "final_loss": round(loss_val, 4)},
+        "roofline": {"kernel": "ema_flat_kernel (momentum update of the key encoder, builder.py:557-567)", "bound": "hbm",
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "bytes_per_launch": ema_bytes, "avg_launch_ms": round(ema_ms, 4)},
+        "step_compute": {"flops_per_img": round(flops_img / 1e9, 2), "unit": "GFLOP (encoders fwd+bwd, flop counter)",
+                         "achieved_tflops_per_gpu": round(flops_img * b / (dt / args.steps) / 1e12, 1),
+                         "frac_of_bf16_dense_peak": round(flops_img * b / (dt / args.steps) / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4)},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.cpu_step import time_cpu_baseline
+        ips, threads, secs = time_cpu_baseline(cfg, synthetic.make_batch, args.cpu_batch, hw, hw, args.queue,
+                                               steps=args.cpu_steps, warmup=1)
+        out["cpu_baseline"] = {"value": round(ips, 3), "unit": "images/sec", "cores": threads, "kind": "port",
+                               "sample": f"{args.cpu_steps} steps of {args.cpu_batch} images ({hw}x{hw}, queue {args.queue}, "
+                                         f"same model) after 1 warm-up step, fp32, {secs:.1f} s"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

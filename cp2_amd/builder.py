@@ -1,0 +1,454 @@
+"""`builder.MODEL` for MI355X: the operator surface reference `main.py` drives
+(kimathikaai/CP2 builder.py:277-304 constructor, :651-665 forward, :1608 on_train_epoch_end,
+:1710 concat_all_gather, enums :30,40,140), with every non-encoder op of the hot path running
+as a hand-written gfx950 kernel from libcp2hip.so:
+
+    reference (builder.py)                         here
+    :1146-1186 mask, compose, strided slices       ops.compose_mask / ops.strided_gather
+    :1204-1257 correlation maps, IoUs (+4b syncs)  ops.corr_iou (device, no sync)
+    :557-567   EMA python loop (~600 launches)     ops.ema_flat over flat parameter buffers (1 launch)
+    :609-649   shuffle-BN gather / scatter         dist.concat_all_gather + ops.gather_rows
+    :1261-1292, 1392-1448  normalise, pool, dense + instance InfoNCE, backward
+                                                   functional.cp2_loss_section (f32 MFMA, 9 launches)
+    :569-587   enqueue (host sync on the pointer)  ops.enqueue (pointer stays on the device)
+
+The encoders (ResNet + ASPP/FCN head) stay in PyTorch-ROCm.  There is no CPU path: forward()
+raises unless the model and its inputs are on the GPU and libcp2hip.so is built.
+"""
+from __future__ import annotations
+
+import copy
+from enum import Enum
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import dist as cdist
+from . import functional as CF
+from . import ops
+from .dist import concat_all_gather  # noqa: F401  (module-level name main.py / callers import from builder)
+from .encoder import build_segmentor
+from .pretrain_types import PretrainType
+
+
+class BackboneType(Enum):
+    DEEPLABV3 = 0
+    UNET_ENCODER_ONLY = 1
+    UNET_TRUNCATED = 2
+
+
+class MappingType(Enum):
+    CP2 = 0
+    PIXEL_ID = 1
+    REGION_ID = 2
+    PIXEL_REGION_ID = 3
+
+
+class NegativeType(Enum):
+    NONE = 0
+    FIXED = 1
+    AVERAGE = 2
+    MEDIAN = 3
+    HARD = 4
+
+
+class AverageMeter(object):
+    """Running value / average (reference builder.py:51-73)."""
+
+    def __init__(self, name, fmt=":f"):
+        self.name, self.fmt = name, fmt
+        self.reset()
+
+    def reset(self):
+        self.val = self.avg = self.sum = self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+    def __str__(self):
+        return ("{name} {val" + self.fmt + "} ({avg" + self.fmt + "})").format(**self.__dict__)
+
+
+class DenseCLNeck(nn.Module):
+    """fc-relu-fc on the pooled map and conv-relu-conv on the grid, plus predictors
+    (reference builder.py:179-274; same sub-module names so checkpoints interchange)."""
+
+    def __init__(self, in_channels, hid_channels, out_channels, num_grid=None):
+        super().__init__()
+        self.avgpool_global = nn.AdaptiveAvgPool2d((1, 1))
+        mlp = lambda a, b, c: nn.Sequential(nn.Linear(a, b), nn.ReLU(inplace=True), nn.Linear(b, c))  # noqa: E731
+        cnv = lambda a, b, c: nn.Sequential(nn.Conv2d(a, b, 1), nn.ReLU(inplace=True), nn.Conv2d(b, c, 1))  # noqa: E731
+        self.global_projector = mlp(in_channels, hid_channels, out_channels)
+        self.global_predictor = mlp(out_channels, hid_channels, out_channels)
+        self.with_pool = num_grid is not None
+        if self.with_pool:
+            self.pool = nn.AdaptiveAvgPool2d((num_grid, num_grid))
+        self.local_projector = cnv(in_channels, hid_channels, out_channels)
+        self.local_predictor = cnv(out_channels, hid_channels, out_channels)
+        self.avgpool_local = nn.AdaptiveAvgPool2d((1, 1))
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.Linear)):
+                nn.init.xavier_normal_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        g = self.avgpool_global(x).flatten(1)
+        g_proj = self.global_projector(g)
+        g_pred = self.global_predictor(g_proj)
+        if self.with_pool:
+            x = self.pool(x)
+        l_proj = self.local_projector(x)
+        l_pred = self.local_predictor(l_proj)
+        return {"x_global_proj": g_proj, "x_local_proj": l_proj, "x_global_pred": g_pred, "x_local_pred": l_pred,
+                "x_avgpool_local_pred": self.avgpool_local(l_pred).flatten(1),
+                "x_avgpool_local_proj": self.avgpool_local(l_proj).flatten(1)}
+
+
+class _QueueInfoNCEFn(torch.autograd.Function):
+    """InfoNCE of row vectors against a queue (reference ContrastiveHead, builder.py:150-176, fed by
+    :762-772 or :866-873): one fused kernel pass, gradients for rows and positives produced in forward."""
+
+    @staticmethod
+    def forward(ctx, rows, pos, queue, temperature, layout, R):
+        need = rows.requires_grad or pos.requires_grad
+        res = ops.rowkey_infonce(rows, layout, R, queue, pos.reshape(R, 1).contiguous(), temperature,
+                                 grad_scale=(1.0 / R) if need else None)
+        if need:
+            ctx.save_for_backward(res.drows, res.dE.reshape(pos.shape))
+        return res.loss
+
+    @staticmethod
+    def backward(ctx, g):
+        drows, dpos = ctx.saved_tensors
+        return drows * g, dpos * g, None, None, None, None
+
+
+def queue_infonce(rows: torch.Tensor, pos: torch.Tensor, queue: torch.Tensor, temperature: float) -> torch.Tensor:
+    """rows: [R,C] (one vector per row) or [b,C,S2] (one vector per pixel, reference layout); pos: R positives."""
+    rows = rows.float().contiguous()
+    if rows.dim() == 2:
+        R, C = rows.shape
+        layout = (1, C, 0, 1)
+    else:
+        b, C, S2 = rows.shape
+        R, layout = b * S2, (S2, C * S2, 1, S2)
+    return _QueueInfoNCEFn.apply(rows, pos.float(), queue, float(temperature), layout, R)
+
+
+class MODEL(nn.Module):
+    def __init__(self, cfg, rank, dim=128, K=65536, m=0.999, instance_logits_temp=0.2, pretrain_from_scratch=False,
+                 include_background=False, lmbd_cp2_dense_loss=0.2, lmbd_pixel_corr_weight=1,
+                 lmbd_region_corr_weight=1, lmbd_not_corr_weight=1, negative_type=NegativeType.NONE,
+                 negative_scale=2, pretrain_type=PretrainType.CP2, backbone_type=BackboneType.DEEPLABV3,
+                 mapping_type=MappingType.CP2, dense_logits_temp=1, unet_truncated_dec_blocks=2, use_predictor=False,
+                 use_avgpool_global=False, use_symmetrical_loss=False, lmbd_coordinate=0, device=None,
+                 # additive knobs (not in the reference)
+                 amp_dtype: Optional[torch.dtype] = None, channels_last: bool = False, log_fn=None):
+        super().__init__()
+        self.queue_len, self.momentum, self.dim = K, m, dim
+        self.temp_global, self.temp_local = instance_logits_temp, dense_logits_temp
+        self.include_background, self.lmbd_dense_loss = include_background, lmbd_cp2_dense_loss
+        self.device, self.rank, self.epoch = device, rank, 0
+        self.use_predictor, self.use_avgpool_global = use_predictor, use_avgpool_global
+        self.use_symmetrical_loss = use_symmetrical_loss
+        assert 0 <= lmbd_coordinate <= 1, f"{lmbd_coordinate = }"
+        self.lmbd_coordinate = lmbd_coordinate
+        assert mapping_type in MappingType
+        self.mapping_type = mapping_type
+        if mapping_type == MappingType.CP2:          # same validation as reference builder.py:329-344
+            assert lmbd_pixel_corr_weight == 1 and lmbd_region_corr_weight == 1 and lmbd_not_corr_weight == 1
+        elif mapping_type == MappingType.PIXEL_ID:
+            assert lmbd_region_corr_weight == 1 and lmbd_pixel_corr_weight > 1
+        elif mapping_type == MappingType.REGION_ID:
+            assert lmbd_pixel_corr_weight == 1 and lmbd_region_corr_weight > 1
+        self.lmbd_pixel_corr_weight = lmbd_pixel_corr_weight
+        self.lmbd_region_corr_weight = lmbd_region_corr_weight
+        self.lmbd_not_corr_weight = lmbd_not_corr_weight
+        assert pretrain_type in PretrainType and negative_type in NegativeType and backbone_type in BackboneType
+        self.pretrain_type, self.negative_type, self.negative_scale = pretrain_type, negative_type, negative_scale
+        self.backbone_type = backbone_type
+        if backbone_type != BackboneType.DEEPLABV3:
+            raise NotImplementedError(f"{backbone_type = }: the U-Net backbones need segmentation_models_pytorch "
+                                      "(out of scope of the MI355X hot path; SURVEY.md section 2.1)")
+        if negative_type != NegativeType.NONE:
+            raise NotImplementedError(f"{negative_type = }: experimental logit reshaping is a 'next' row (SURVEY 8f-4)")
+        self.amp_dtype, self.channels_last, self.log_fn = amp_dtype, channels_last, log_fn
+
+        self.encoder_q = build_segmentor(cfg.model, train_cfg=cfg.get("train_cfg"), test_cfg=cfg.get("test_cfg"))
+        self.encoder_k = build_segmentor(cfg.model, train_cfg=cfg.get("train_cfg"), test_cfg=cfg.get("test_cfg"))
+        print(f"[INFO] Initializing with imagenet weights: {not pretrain_from_scratch}")
+        if not pretrain_from_scratch:
+            self.encoder_q.backbone.init_weights()
+            self.encoder_k.backbone.init_weights()
+
+        # output strides from a CPU dry run, as the reference does (builder.py:393-402)
+        probe = torch.rand(2, 3, 224, 224)
+        self.output_stride = int(probe.shape[2] / self.encoder_q(probe).shape[2])
+        print(f"{self.output_stride = }")
+        self.backbone_output_stride = int(probe.shape[2] / self.encoder_q.backbone(torch.rand(2, 3, 224, 224))[3].shape[2])
+        print(f"{self.backbone_output_stride = }")
+
+        if pretrain_type in (PretrainType.BYOL, PretrainType.MOCO):
+            raise NotImplementedError(f"{pretrain_type = }: image-level baselines are outside the CP2 hot path")
+        elif pretrain_type == PretrainType.CP2:
+            assert self.negative_type == NegativeType.NONE and self.mapping_type == MappingType.CP2
+        elif pretrain_type in (PretrainType.DENSECL, PretrainType.PROPOSED_V2):
+            feat = self.encoder_q.backbone.feat_dim
+            self.encoder_q.neck = DenseCLNeck(in_channels=feat, hid_channels=2048, out_channels=self.dim)
+            self.encoder_k.neck = DenseCLNeck(in_channels=feat, hid_channels=2048, out_channels=self.dim)
+            assert self.momentum == 0.999 and self.lmbd_dense_loss == 0.5, (self.momentum, self.lmbd_dense_loss)
+            assert self.temp_global == 0.2 and self.temp_local == 0.2, (self.temp_global, self.temp_local)
+            if pretrain_type == PretrainType.DENSECL:
+                assert not (use_predictor or use_avgpool_global or use_symmetrical_loss) and lmbd_coordinate == 0
+        for pq, pk in zip(self.encoder_q.parameters(), self.encoder_k.parameters()):
+            pk.data.copy_(pq.data)
+            pk.requires_grad = False
+
+        self.register_buffer("queue", F.normalize(torch.randn(self.dim, self.queue_len), dim=0))
+        self.register_buffer("queue_ptr", torch.zeros(1, dtype=torch.long))
+        self.register_buffer("queue2", F.normalize(torch.randn(self.dim, self.queue_len), dim=0))
+        self.register_buffer("queue2_ptr", torch.zeros(1, dtype=torch.long))
+
+        self.loss_o = AverageMeter("Loss_overall", ":.4f")
+        self.loss_i = AverageMeter("Loss_ins", ":.4f")
+        self.loss_d = AverageMeter("Loss_den", ":.4f")
+        self.acc_ins = AverageMeter("Acc_ins", ":6.2f")
+        self.acc_seg = AverageMeter("Acc_seg", ":6.2f")
+        self.cross_image_variance_source = AverageMeter("Cross_Image_Variance_Source", ":6.2f")
+        self.cross_image_variance_target = AverageMeter("Cross_Image_Variance_Target", ":6.2f")
+        self.correlation_ious, self.masked_correlation_ious = [], []
+        self._flat_q = self._flat_k = None
+        self.ema_in_forward = True       # False: the caller runs _momentum_update_key_encoder() itself before forward
+        self._pending_logs = []          # device scalars waiting for one batched device->host copy
+        self.sync_logs_every = 0         # 0: only when flush_logs() / on_train_epoch_end() is called
+
+    # ------------------------------------------------------------------ parameters as flat buffers
+    def flatten_parameters(self):
+        """Re-home every encoder parameter into one contiguous fp32 buffer per encoder (same offsets
+        in both), so the EMA is a single streaming kernel over 12 bytes per parameter.  Idempotent;
+        called lazily by the first forward (after .to(device) / DDP wrapping)."""
+        pq, pk = list(self.encoder_q.parameters()), list(self.encoder_k.parameters())
+        dev = pq[0].device
+        if self._flat_q is not None and self._flat_q.device == dev and \
+                all(p.data_ptr() == self._flat_q.data_ptr() + 4 * o for p, o in zip(pq, self._flat_offsets)):
+            return
+        offs, total = [], 0
+        for p in pq:
+            offs.append(total)
+            total += (p.numel() + 63) // 64 * 64            # 256-byte aligned slots
+        flat_q = torch.zeros(total, dtype=torch.float32, device=dev)
+        flat_k = torch.zeros(total, dtype=torch.float32, device=dev)
+        for p, k, o in zip(pq, pk, offs):
+            assert p.dtype == torch.float32 and k.shape == p.shape
+            flat_q[o:o + p.numel()].copy_(p.data.reshape(-1))
+            flat_k[o:o + p.numel()].copy_(k.data.reshape(-1))
+            p.data = flat_q[o:o + p.numel()].view(p.shape)
+            k.data = flat_k[o:o + p.numel()].view(p.shape)
+        self._flat_q, self._flat_k, self._flat_offsets = flat_q, flat_k, offs
+
+    @torch.no_grad()
+    def _momentum_update_key_encoder(self):
+        """theta_k = theta_k*m + theta_q*(1-m) for every encoder parameter (reference builder.py:557-567)."""
+        self.flatten_parameters()
+        ops.ema_flat(self._flat_k, self._flat_q, self.momentum)
+
+    # ------------------------------------------------------------------ queue
+    @torch.no_grad()
+    def _dequeue_and_enqueue(self, keys):
+        ops.enqueue(self.queue, concat_all_gather(keys.contiguous()), self.queue_ptr)
+
+    @torch.no_grad()
+    def _dequeue_and_enqueue2(self, keys):
+        ops.enqueue(self.queue2, concat_all_gather(keys.contiguous()), self.queue2_ptr)
+
+    # ------------------------------------------------------------------ shuffle-BN
+    @torch.no_grad()
+    def _batch_shuffle_ddp(self, x, idx_shuffle=None):
+        x_gather = concat_all_gather(x.contiguous())
+        w = cdist.world_size()
+        if idx_shuffle is None:
+            idx_shuffle = cdist.make_shuffle_index(x_gather.shape[0], x.device)
+        idx_unshuffle = torch.argsort(idx_shuffle)
+        taken = ops.gather_rows(x_gather, cdist.shuffle_rows_for_rank(idx_shuffle, cdist.rank(), w).contiguous())
+        return taken, idx_unshuffle
+
+    @torch.no_grad()
+    def _batch_unshuffle_ddp(self, x, idx_unshuffle):
+        w = cdist.world_size()
+        x_gather = concat_all_gather(x.float().contiguous())
+        return ops.gather_rows(x_gather, idx_unshuffle.view(w, -1)[cdist.rank()].contiguous())
+
+    # ------------------------------------------------------------------ dispatch
+    def forward(self, **kwargs):
+        if self.pretrain_type in (PretrainType.CP2, PretrainType.PROPOSED):
+            return self.forward_cp2(**kwargs)
+        if self.pretrain_type in (PretrainType.DENSECL, PretrainType.PROPOSED_V2):
+            return self.forward_densecl(**kwargs)
+        raise NotImplementedError(f"{self.pretrain_type = }")
+
+    def _encode(self, enc, img):
+        if self.channels_last:
+            img = img.contiguous(memory_format=torch.channels_last)
+        if self.amp_dtype is not None:
+            with torch.autocast("cuda", dtype=self.amp_dtype):
+                return enc(img)
+        return enc(img)
+
+    # ------------------------------------------------------------------ CP2
+    def forward_cp2(self, img_a, img_b, bg0, bg1, visualize, step, new_epoch, pixel_ids_a, pixel_ids_b,
+                    region_ids_a, region_ids_b, idx_shuffle=None):
+        s = self.output_stride
+        b = img_a.shape[0]
+        img_a, _, mask_a = ops.compose_mask(img_a.contiguous(), bg0.contiguous(), s)
+        img_b, _, mask_b = ops.compose_mask(img_b.contiguous(), bg1.contiguous(), s)
+        mask_a, mask_b = mask_a.reshape(b, -1), mask_b.reshape(b, -1)
+        region_a = ops.strided_gather(region_ids_a.contiguous(), s).reshape(b, -1)
+        region_b = ops.strided_gather(region_ids_b.contiguous(), s).reshape(b, -1)
+        ids = None
+        weights = (float(self.lmbd_pixel_corr_weight), float(self.lmbd_region_corr_weight), float(self.lmbd_not_corr_weight))
+        if weights != (1.0, 1.0, 1.0):
+            pixel_a = ops.strided_gather(pixel_ids_a.contiguous(), s).reshape(b, -1)
+            pixel_b = ops.strided_gather(pixel_ids_b.contiguous(), s).reshape(b, -1)
+            ids = (pixel_a, pixel_b, region_a, region_b)
+        iou, iou_masked = ops.corr_iou(region_a, region_b, mask_a, mask_b)      # logged per epoch, stays on device
+        self.correlation_ious.append(iou)
+        self.masked_correlation_ious.append(iou_masked)
+
+        q = self._encode(self.encoder_q, img_a).float()                          # queries: b x C x h x w
+        with torch.no_grad():
+            if self.ema_in_forward:
+                self._momentum_update_key_encoder()
+            img_b, idx_unshuffle = self._batch_shuffle_ddp(img_b, idx_shuffle)
+            k = self._encode(self.encoder_k, img_b)
+            k = self._batch_unshuffle_ddp(k, idx_unshuffle)
+
+        out = CF.cp2_loss_section(q, k, mask_a, mask_b, self.queue, temp_global=self.temp_global,
+                                  temp_local=self.temp_local, lmbd_dense=self.lmbd_dense_loss,
+                                  include_background=self.include_background, ids=ids, weights=weights)
+        self._dequeue_and_enqueue(out.k_pos)
+        self._log_step(step, b, {"train/loss_step": out.loss.detach(), "train/loss_ins_step": out.loss_instance,
+                                 "train/loss_dense_step": out.loss_dense, "train/acc_ins_step": out.acc1,
+                                 "train/acc_seg_step": out.acc_dense,
+                                 "train/+ive_scores_step": out.dense_sample[:, 3].mean(),
+                                 "train/-ive_scores_step": out.dense_sample[:, 4].mean(),
+                                 "step/instance_average_positive_scores": out.instance_pos.mean()})
+        if new_epoch:
+            self.epoch += 1
+        return out.loss
+
+    # ------------------------------------------------------------------ DenseCL (BASELINE config 5)
+    def forward_densecl(self, img_a, img_b, bg0, bg1, visualize, step, new_epoch, pixel_ids_a, pixel_ids_b,
+                        region_ids_a, region_ids_b, idx_shuffle=None):
+        bs = self.backbone_output_stride
+        b = img_a.shape[0]
+        pix_a = ops.strided_gather(pixel_ids_a.contiguous(), bs).reshape(b, -1)
+        pix_b = ops.strided_gather(pixel_ids_b.contiguous(), bs).reshape(b, -1)
+
+        def query_features(img):
+            embd = self._encode(self.encoder_q.backbone, img)[3].float()
+            out = self.encoder_q.neck(embd)
+            local = out["x_local_pred"] if self.use_predictor else out["x_local_proj"]
+            glob = out["x_global_pred"] if self.use_predictor else out["x_global_proj"]
+            if self.use_avgpool_global:
+                glob = out["x_avgpool_local_pred"] if self.use_predictor else out["x_avgpool_local_proj"]
+            return F.normalize(embd.flatten(2), dim=1), F.normalize(local.flatten(2), dim=1), F.normalize(glob, dim=1)
+
+        @torch.no_grad()
+        def key_features(img):
+            if self.ema_in_forward:
+                self._momentum_update_key_encoder()
+            img, idx_un = self._batch_shuffle_ddp(img, idx_shuffle)
+            embd = self._encode(self.encoder_k.backbone, img)[3].float()
+            out = self.encoder_k.neck(embd)
+            glob = out["x_avgpool_local_proj"] if self.use_avgpool_global else out["x_global_proj"]
+            feats = (F.normalize(embd.flatten(2), dim=1), F.normalize(out["x_local_proj"].flatten(2), dim=1),
+                     F.normalize(glob, dim=1), F.normalize(out["x_avgpool_local_proj"], dim=1))
+            return tuple(self._batch_unshuffle_ddp(f, idx_un) for f in feats)
+
+        def global_loss(qg, kg):
+            return queue_infonce(qg, (qg * kg).sum(1), self.queue, self.temp_global)
+
+        def local_loss(q_embed, k_embed, q_local, k_local, ids_q, ids_k):
+            # positives by backbone-feature arg-max, optionally mixed with coordinate matches (builder.py:818-855)
+            best = torch.bmm(q_embed.transpose(1, 2), k_embed).argmax(dim=2)
+            local_sim = torch.bmm(q_local.transpose(1, 2), k_local)
+            pos = torch.gather(local_sim, 2, best.unsqueeze(2)).squeeze(2)
+            if self.lmbd_coordinate > 0:
+                corr = ids_q[:, :, None] == ids_k[:, None, :]
+                overlap = corr.any(-1)
+                coord = (local_sim * corr).sum(-1)
+                pos = torch.where(overlap, pos * (1 - self.lmbd_coordinate) + coord * self.lmbd_coordinate, pos)
+            return queue_infonce(q_local, pos.reshape(-1), self.queue2, self.temp_local)
+
+        eq, lq, gq = query_features(img_a)
+        ek, lk, gk, pooled_k = key_features(img_b)
+        loss_global, loss_local = global_loss(gq, gk), local_loss(eq, ek, lq, lk, pix_a, pix_b)
+        update = (gk, pooled_k)
+        if self.use_symmetrical_loss:
+            eq2, lq2, gq2 = query_features(img_b)
+            ek2, lk2, gk2, pooled_k2 = key_features(img_a)
+            loss_global = loss_global + global_loss(gq2, gk2)
+            loss_local = loss_local + local_loss(eq2, ek2, lq2, lk2, pix_b, pix_a)
+            if step % 2 == 0:
+                update = (gk2, pooled_k2)
+        loss = (1 - self.lmbd_dense_loss) * loss_global + self.lmbd_dense_loss * loss_local
+        self._dequeue_and_enqueue(update[0])
+        self._dequeue_and_enqueue2(update[1])
+        self._log_step(step, b, {"train/loss_step": loss.detach(), "train/loss_ins_step": loss_global.detach(),
+                                 "train/loss_dense_step": loss_local.detach()})
+        return loss
+
+    # ------------------------------------------------------------------ logging without per-step host syncs
+    def _log_step(self, step, n, scalars):
+        """The reference calls .item() several times per step (builder.py:1553-1604).  Here the scalars
+        stay on the device; flush_logs() moves everything queued so far in one copy."""
+        names = list(scalars)
+        self._pending_logs.append((step, n, names, torch.stack([scalars[k].detach().float().reshape(()) for k in names])))
+        if self.sync_logs_every and len(self._pending_logs) >= self.sync_logs_every:
+            self.flush_logs()
+
+    def flush_logs(self):
+        if not self._pending_logs:
+            return []
+        vals = torch.stack([p[3] for p in self._pending_logs]).cpu().tolist() if \
+            len({len(p[2]) for p in self._pending_logs}) == 1 else [p[3].cpu().tolist() for p in self._pending_logs]
+        meters = {"train/loss_step": self.loss_o, "train/loss_ins_step": self.loss_i, "train/loss_dense_step": self.loss_d,
+                  "train/acc_ins_step": self.acc_ins, "train/acc_seg_step": self.acc_seg}
+        out = []
+        for (step, n, names, _), row in zip(self._pending_logs, vals):
+            rec = dict(zip(names, row))
+            for k, meter in meters.items():
+                if k in rec:
+                    meter.update(rec[k], n)
+            if self.rank == 0 and self.log_fn is not None:
+                self.log_fn(dict(rec, **{"update-step": step}))
+            out.append((step, rec))
+        self._pending_logs = []
+        return out
+
+    def epoch_ious(self):
+        """(iou, iou_masked) lists accumulated since the last call (reference keeps python lists, :1254-1257)."""
+        cat = lambda xs: torch.cat(xs).cpu().tolist() if xs else []  # noqa: E731
+        r = cat(self.correlation_ious), cat(self.masked_correlation_ious)
+        self.correlation_ious, self.masked_correlation_ious = [], []
+        return r
+
+    def on_train_epoch_end(self, step):
+        self.flush_logs()
+        if self.rank == 0 and self.log_fn is not None:
+            rec = {"train/loss": self.loss_o.avg, "train/loss_ins": self.loss_i.avg, "train/loss_dense": self.loss_d.avg}
+            if self.pretrain_type in (PretrainType.CP2, PretrainType.PROPOSED):
+                rec.update({"train/acc_ins": self.acc_ins.avg, "train/acc_seg": self.acc_seg.avg})
+            self.log_fn(rec)
+        self.reset_metrics()
+
+    def reset_metrics(self):
+        for m in (self.loss_o, self.loss_i, self.loss_d, self.acc_ins, self.acc_seg,
+                  self.cross_image_variance_source, self.cross_image_variance_target):
+            m.reset()

@@ -1,0 +1,272 @@
+"""Encoder surface below the hot path: ResNet + ASPP / FCN head with `contrast=True`.
+
+The reference obtains this from the external `mmseg` package
+(`build_segmentor(cfg.model)`, builder.py:366-371); the only in-tree picture of it is
+the vendored mmseg_/models/{backbones/resnet.py, decode_heads/*.py,
+segmentors/encoder_decoder.py}.  This file restates that surface in plain torch.nn so
+the step runs without mmseg/mmcv, keeping
+  * the call contract:  enc(img) -> [b,128,H/os,W/os];  enc.backbone(img) -> 4 stage maps;
+    enc.backbone.init_weights()            (encoder_decoder.py:137-140, resnet.py:632-647)
+  * the parameter names of a mmseg checkpoint: backbone.conv1 / bn1 / layer{1..4}.{i}.
+    conv{1,2,3} / bn{1,2,3} / downsample.{0,1};  decode_head.image_pool.1.{conv,bn},
+    aspp_modules.{i}.{conv,bn}, bottleneck.{conv,bn}, convs.{i}.{conv,bn}, conv_cat,
+    contrast_conv.{0,2}, conv_seg          (resnet.py:161-206,567-579; aspp_head.py:69-97;
+                                            fcn_head.py:41-79; decode_head.py:84)
+The encoder stays in PyTorch-ROCm (MIOpen / hipBLASLt) by design (north_star): it is
+plumbing around the hand-written kernels, not part of them.
+"""
+from __future__ import annotations
+
+import os
+import warnings
+from typing import Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class ConvBNAct(nn.Module):
+    """conv -> BN -> ReLU with mmcv ConvModule's sub-module names (`conv`, `bn`, `activate`)."""
+
+    def __init__(self, cin, cout, k, padding=0, dilation=1, norm=True):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, padding=padding, dilation=dilation, bias=not norm)
+        if norm:
+            self.bn = nn.BatchNorm2d(cout)
+        self.activate = nn.ReLU(inplace=True)
+        self.with_norm = norm
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.with_norm:
+            x = self.bn(x)
+        return self.activate(x)
+
+
+def _downsample(cin, cout, stride):
+    return nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride, bias=False), nn.BatchNorm2d(cout))
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        return self.relu(y + idt)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None):
+        super().__init__()   # style='pytorch': the stride sits on the 3x3 conv
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        return self.relu(y + idt)
+
+
+_ARCH = {18: (BasicBlock, (2, 2, 2, 2)), 34: (BasicBlock, (3, 4, 6, 3)), 50: (Bottleneck, (3, 4, 6, 3)),
+         101: (Bottleneck, (3, 4, 23, 3)), 152: (Bottleneck, (3, 8, 36, 3))}
+
+
+class ResNet(nn.Module):
+    def __init__(self, depth=50, in_channels=3, stem_channels=64, base_channels=64, num_stages=4,
+                 strides=(1, 2, 2, 2), dilations=(1, 1, 1, 1), out_indices=(0, 1, 2, 3), style="pytorch",
+                 contract_dilation=False, zero_init_residual=True, norm_cfg=None, norm_eval=False,
+                 init_cfg=None, **unused):
+        super().__init__()
+        if depth not in _ARCH:
+            raise KeyError(f"invalid depth {depth} for resnet")
+        if style != "pytorch":
+            raise NotImplementedError("only style='pytorch' is restated")
+        block, blocks = _ARCH[depth]
+        self.depth, self.out_indices, self.norm_eval = depth, tuple(out_indices), norm_eval
+        self.zero_init_residual, self.init_cfg = zero_init_residual, init_cfg
+        self.conv1 = nn.Conv2d(in_channels, stem_channels, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(stem_channels)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        inplanes = stem_channels
+        self.res_layers = []
+        for i, nb in enumerate(blocks[:num_stages]):
+            planes = base_channels * 2 ** i
+            stride, dil = strides[i], dilations[i]
+            first_dil = dil // 2 if (dil > 1 and contract_dilation) else dil
+            down = _downsample(inplanes, planes * block.expansion, stride) \
+                if (stride != 1 or inplanes != planes * block.expansion) else None
+            layers = [block(inplanes, planes, stride, first_dil, down)]
+            inplanes = planes * block.expansion
+            layers += [block(inplanes, planes, 1, dil) for _ in range(1, nb)]
+            name = f"layer{i + 1}"
+            self.add_module(name, nn.Sequential(*layers))
+            self.res_layers.append(name)
+        self.feat_dim = inplanes
+
+    def init_weights(self, pretrained=None):
+        """ImageNet initialisation when a LOCAL checkpoint is configured and present
+        (the reference's default 'torchvision://resnet50' needs the network: configs/config_pretrain.py:3,18);
+        otherwise Kaiming / constant init as mmseg does without a checkpoint (resnet.py:600-630)."""
+        ckpt = pretrained or (self.init_cfg or {}).get("checkpoint")
+        if ckpt and os.path.isfile(str(ckpt)):
+            state = torch.load(ckpt, map_location="cpu")
+            state = state.get("state_dict", state)
+            missing, unexpected = self.load_state_dict(state, strict=False)
+            print(f"[cp2_amd] backbone weights from {ckpt}: {len(missing)} missing, {len(unexpected)} unexpected")
+            return
+        if ckpt:
+            warnings.warn(f"backbone checkpoint {ckpt!r} is not a local file (no network here): random init")
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+        if self.zero_init_residual:
+            for m in self.modules():
+                if isinstance(m, Bottleneck):
+                    nn.init.zeros_(m.bn3.weight)
+                elif isinstance(m, BasicBlock):
+                    nn.init.zeros_(m.bn2.weight)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        outs = []
+        for i, name in enumerate(self.res_layers):
+            x = getattr(self, name)(x)
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(outs)
+
+    def train(self, mode=True):
+        super().train(mode)
+        if mode and self.norm_eval:
+            for m in self.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.eval()
+        return self
+
+
+class _DecodeHead(nn.Module):
+    def __init__(self, in_channels, channels, num_classes, dropout_ratio=0.1, in_index=-1, align_corners=False,
+                 contrast=False, **unused):
+        super().__init__()
+        self.in_channels, self.channels, self.num_classes = in_channels, channels, num_classes
+        self.in_index, self.align_corners, self.contrast = in_index, align_corners, contrast
+        self.conv_seg = nn.Conv2d(channels, num_classes, 1)
+        self.dropout = nn.Dropout2d(dropout_ratio) if dropout_ratio > 0 else None
+        nn.init.normal_(self.conv_seg.weight, mean=0.0, std=0.01)
+        nn.init.zeros_(self.conv_seg.bias)
+
+    def _add_contrast(self):
+        if self.contrast:     # aspp_head.py:93-97 / fcn_head.py:75-79: the 128-d 1x1-conv projector
+            self.contrast_conv = nn.Sequential(nn.Conv2d(self.channels, self.channels, 1), nn.ReLU(),
+                                               nn.Conv2d(self.channels, 128, 1))
+            # conv_seg never receives a gradient on the contrast path; freezing it keeps its
+            # state-dict entry while letting DDP run without find_unused_parameters.
+            self.conv_seg.requires_grad_(False)
+
+    def cls_seg(self, feat):
+        if self.dropout is not None:
+            feat = self.dropout(feat)
+        return self.conv_seg(feat)
+
+    def _finish(self, feat):
+        return self.contrast_conv(feat) if self.contrast else self.cls_seg(feat)
+
+
+class ASPPHead(_DecodeHead):
+    def __init__(self, dilations=(1, 6, 12, 18), **kw):
+        super().__init__(**kw)
+        cin, ch = self.in_channels, self.channels
+        self.image_pool = nn.Sequential(nn.AdaptiveAvgPool2d(1), ConvBNAct(cin, ch, 1))
+        self.aspp_modules = nn.ModuleList(
+            [ConvBNAct(cin, ch, 1 if d == 1 else 3, padding=0 if d == 1 else d, dilation=d) for d in dilations])
+        self.bottleneck = ConvBNAct((len(dilations) + 1) * ch, ch, 3, padding=1)
+        self._add_contrast()
+
+    def forward(self, inputs):
+        x = inputs[self.in_index]
+        pooled = F.interpolate(self.image_pool(x), size=x.shape[2:], mode="bilinear", align_corners=self.align_corners)
+        feats = torch.cat([pooled] + [m(x) for m in self.aspp_modules], dim=1)
+        return self._finish(self.bottleneck(feats))
+
+
+class FCNHead(_DecodeHead):
+    def __init__(self, num_convs=2, kernel_size=3, concat_input=True, dilation=1, **kw):
+        super().__init__(**kw)
+        cin, ch = self.in_channels, self.channels
+        if num_convs == 0:
+            assert cin == ch
+            self.convs = nn.Identity()
+        else:
+            pad = (kernel_size // 2) * dilation
+            self.convs = nn.Sequential(*[ConvBNAct(cin if i == 0 else ch, ch, kernel_size, padding=pad, dilation=dilation)
+                                         for i in range(num_convs)])
+        self.concat_input = concat_input
+        if concat_input:
+            self.conv_cat = ConvBNAct(cin + ch, ch, kernel_size, padding=kernel_size // 2)
+        self._add_contrast()
+
+    def forward(self, inputs):
+        x = inputs[self.in_index]
+        y = self.convs(x)
+        if self.concat_input:
+            y = self.conv_cat(torch.cat([x, y], dim=1))
+        return self._finish(y)
+
+
+class EncoderDecoder(nn.Module):
+    """backbone + decode_head; `forward(img)` returns the head output on the feature grid
+    (mmseg_/models/segmentors/encoder_decoder.py:137-140 with a `contrast` head)."""
+
+    def __init__(self, backbone: nn.Module, decode_head: nn.Module):
+        super().__init__()
+        self.backbone, self.decode_head = backbone, decode_head
+
+    def extract_feat(self, img):
+        return self.backbone(img)
+
+    def forward(self, img):
+        return self.decode_head(self.backbone(img))
+
+
+_BACKBONES = {"ResNet": ResNet}
+_HEADS = {"ASPPHead": ASPPHead, "FCNHead": FCNHead}
+
+
+def build_segmentor(model_cfg, train_cfg=None, test_cfg=None) -> EncoderDecoder:
+    """Same call shape as mmseg.models.build_segmentor (mmseg_/models/builder.py:35-46) for the
+    config schema of configs/config_pretrain.py / config_moco.py."""
+    cfg = dict(model_cfg)
+    if cfg.get("type", "EncoderDecoder") != "EncoderDecoder":
+        raise NotImplementedError(f"segmentor type {cfg.get('type')!r}")
+    bb = dict(cfg["backbone"])
+    hd = dict(cfg["decode_head"])
+    backbone = _BACKBONES[bb.pop("type")](**bb)
+    hd.pop("norm_cfg", None), hd.pop("loss_decode", None)
+    head = _HEADS[hd.pop("type")](**hd)
+    return EncoderDecoder(backbone, head)

@@ -1,0 +1,247 @@
+"""`python -m cp2_amd.main ...` -- the pre-training CLI of reference main.py on MI355X.
+
+Every flag of reference main.py:37-132 is accepted with the same name, type and default, so the
+authors' launch scripts keep working; additive flags are grouped at the end of get_args().
+One process per GPU: either started by torchrun (RANK / LOCAL_RANK / WORLD_SIZE in the env) or,
+as the reference does (main.py:732), spawned here with --world-size N.  Collectives run on RCCL
+(`--dist-backend nccl` is RCCL on ROCm).  Real-image loading (albumentations / cv2 pipelines of
+reference loader.py) is outside this hot path: `--synthetic` feeds on-device batches with the
+loader's output contract.
+"""
+from __future__ import annotations
+
+import argparse
+import math
+import os
+import shutil
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch.nn.parallel import DistributedDataParallel
+
+from . import builder, synthetic
+from .config import Config
+from .engine import TrainStep
+from .pretrain_types import PretrainType
+
+DEFAULT_QUEUE_SIZE = 65536
+
+
+def get_args(argv=None):
+    # fmt: off
+    p = argparse.ArgumentParser(description="Copy-Paste Contrastive Pretraining (MI355X-native)")
+    p.add_argument("--config", help="path to configuration file")
+    p.add_argument("--run_id", required=True, type=str)
+    p.add_argument("--tags", nargs="+", default=[])
+    p.add_argument("--offline_wandb", action="store_true")
+    p.add_argument("--debug", action="store_true")
+    p.add_argument("--pretrain_from_scratch", action="store_true")
+    p.add_argument("--use_predictor", action="store_true")
+    p.add_argument("--use_avgpool_global", action="store_true")
+    p.add_argument("--use_symmetrical_loss", action="store_true")
+    p.add_argument("--lmbd_coordinate", default=0, type=float)
+    p.add_argument("--log_dir", type=str, required=True)
+    p.add_argument("--wandb_project", type=str, default="ssl-pretraining")
+    p.add_argument("--wandb_team", type=str, default="critical-ml-dg")
+    p.add_argument("--data_dirs", metavar="DIR", nargs="+", default=[])
+    p.add_argument("--directory_type", type=str, default="FILENAME")
+    p.add_argument("--backbone_type", type=str, choices=[x.name for x in builder.BackboneType], default=builder.BackboneType.DEEPLABV3.name)
+    p.add_argument("--pretrain_type", type=str, choices=[x.name for x in PretrainType], default=PretrainType.CP2.name)
+    p.add_argument("--mapping_type", type=str, choices=[x.name for x in builder.MappingType], default=builder.MappingType.CP2.name)
+    p.add_argument("--negative_type", type=str, choices=[x.name for x in builder.NegativeType], default=builder.NegativeType.NONE.name)
+    p.add_argument("--negative_scale", type=float, default=2)
+    p.add_argument("--num-workers", default=32, type=int)
+    p.add_argument("--lmbd_cp2_dense_loss", default=0.2, type=float)
+    p.add_argument("--lmbd_region_corr_weight", default=1, type=float)
+    p.add_argument("--lmbd_pixel_corr_weight", default=1, type=float)
+    p.add_argument("--lmbd_not_corr_weight", default=1, type=float)
+    p.add_argument("--pixel_ids_stride", default=1, type=int)
+    p.add_argument("--unet_truncated_dec_blocks", default=2, type=int)
+    p.add_argument("--same_foreground", action="store_true")
+    p.add_argument("--cap_queue", action="store_true")
+    p.add_argument("--include_background", action="store_true")
+    p.add_argument("--dense_logits_temp", default=1, type=float)
+    p.add_argument("--instance_logits_temp", default=0.2, type=float)
+    p.add_argument("--lemon_data", action="store_true")
+    p.add_argument("--img_height", default=224, type=int)
+    p.add_argument("--img_width", default=224, type=int)
+    p.add_argument("--foreground_min", default=0.5, type=float)
+    p.add_argument("--foreground_max", default=0.8, type=float)
+    p.add_argument("--dist-url", default="tcp://127.0.0.1:10001", type=str)
+    p.add_argument("--dist-backend", default="nccl", type=str)
+    p.add_argument("--world-size", default=1, type=int)
+    p.add_argument("--epochs", default=200, type=int)
+    p.add_argument("--max_steps", default=np.inf, type=float)
+    p.add_argument("--num-images", default=1281167, type=int)
+    p.add_argument("--start-epoch", default=0, type=int)
+    p.add_argument("-b", "--batch-size", default=256, type=int, help="total batch size over all GPUs")
+    p.add_argument("--lr", "--learning-rate", default=0.03, type=float, dest="lr")
+    p.add_argument("--remove_lr_scheduler", action="store_true")
+    p.add_argument("--momentum", default=0.9, type=float)
+    p.add_argument("--optim", default="sgd")
+    p.add_argument("--wd", "--weight-decay", default=1e-4, type=float, dest="weight_decay")
+    p.add_argument("-p", "--print-freq", default=10, type=int)
+    p.add_argument("--scalar-freq", default=100, type=int)
+    p.add_argument("--ckpt-freq", default=100, type=int)
+    p.add_argument("--resume", default="", type=str)
+    p.add_argument("--seed", default=0, type=int)
+    # ---- additive (not in the reference)
+    p.add_argument("--queue_size", default=DEFAULT_QUEUE_SIZE, type=int, help="MoCo queue length K (reference: fixed 65536)")
+    p.add_argument("--synthetic", action="store_true", help="on-device synthetic batches (loader contract of SURVEY 8d)")
+    p.add_argument("--steps_per_epoch", default=100, type=int, help="with --synthetic: steps per epoch")
+    p.add_argument("--amp", default="bf16", choices=["none", "bf16"], help="encoder autocast dtype")
+    p.add_argument("--no_channels_last", action="store_true")
+    p.add_argument("--graph", action="store_true", help="capture the whole step in a hipGraph (single GPU)")
+    # fmt: on
+    args = p.parse_args(argv)
+    args.pretrain_type = PretrainType[args.pretrain_type]
+    args.backbone_type = builder.BackboneType[args.backbone_type]
+    args.mapping_type = builder.MappingType[args.mapping_type]
+    args.negative_type = builder.NegativeType[args.negative_type]
+    if args.lemon_data:
+        args.img_height = args.img_width = 512
+    if args.pretrain_type == PretrainType.DENSECL:          # reference main.py:148-153
+        args.dense_logits_temp = args.instance_logits_temp = 0.2
+        args.use_predictor = False
+        args.lmbd_cp2_dense_loss = 0.5
+        assert args.pixel_ids_stride == 1
+    if args.pretrain_type == PretrainType.PROPOSED_V2:
+        assert args.pixel_ids_stride == 1
+    return args
+
+
+def make_optimizer(params, args, device, capturable: bool):
+    """SGD(momentum, wd) / AdamW as reference main.py:467-477.  For hipGraph capture the learning rate is
+    a device tensor and the update is torch's fused multi-tensor kernel, so the LR schedule needs no re-capture."""
+    lr = torch.tensor(float(args.lr), device=device) if capturable else args.lr
+    if args.optim == "adamw":
+        return torch.optim.AdamW(params, lr, weight_decay=0.01, fused=capturable or None, capturable=capturable)
+    if args.optim == "sgd":
+        return torch.optim.SGD(params, lr, momentum=args.momentum, weight_decay=args.weight_decay,
+                               fused=True if capturable else None)
+    raise NotImplementedError("Only sgd and adamw optimizers are supported.")
+
+
+def adjust_learning_rate(optimizer, epoch, args):
+    lr = args.lr * 0.5 * (1.0 + math.cos(math.pi * epoch / args.epochs))     # reference main.py:693-698
+    for g in optimizer.param_groups:
+        if isinstance(g["lr"], torch.Tensor):
+            g["lr"].fill_(lr)
+        else:
+            g["lr"] = lr
+    return lr
+
+
+def save_checkpoint(state, is_best, epoch, filename="checkpoint.ckpt"):
+    torch.save(state, filename)                                               # reference main.py:661-670
+    if is_best:
+        shutil.copyfile(filename, os.path.join(Path(filename).parent, "checkpoint.ckpt"))
+
+
+def build_model(args, cfg, rank, device):
+    m_val = 0.999 if args.pretrain_type in (PretrainType.CP2, PretrainType.PROPOSED, PretrainType.DENSECL,
+                                            PretrainType.PROPOSED_V2) else 0.996
+    K = min(args.num_images, args.queue_size) if args.cap_queue else args.queue_size
+    return builder.MODEL(
+        cfg, m=m_val, K=K, dim=128, pretrain_from_scratch=args.pretrain_from_scratch,
+        include_background=args.include_background, lmbd_cp2_dense_loss=args.lmbd_cp2_dense_loss,
+        pretrain_type=args.pretrain_type, backbone_type=args.backbone_type, mapping_type=args.mapping_type,
+        negative_type=args.negative_type, negative_scale=args.negative_scale,
+        lmbd_pixel_corr_weight=args.lmbd_pixel_corr_weight, lmbd_region_corr_weight=args.lmbd_region_corr_weight,
+        lmbd_not_corr_weight=args.lmbd_not_corr_weight, dense_logits_temp=args.dense_logits_temp,
+        instance_logits_temp=args.instance_logits_temp, unet_truncated_dec_blocks=args.unet_truncated_dec_blocks,
+        use_predictor=args.use_predictor, use_avgpool_global=args.use_avgpool_global,
+        use_symmetrical_loss=args.use_symmetrical_loss, lmbd_coordinate=args.lmbd_coordinate, device=device, rank=rank,
+        amp_dtype=torch.bfloat16 if args.amp == "bf16" else None, channels_last=not args.no_channels_last)
+
+
+def main_worker(rank, args):
+    world = args.world_size
+    if not torch.cuda.is_available():
+        raise RuntimeError("cp2_amd.main needs a GPU: the CP2 hot path has no CPU implementation "
+                           "(the CPU baseline lives in oracle/ and is driven by bench.py)")
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    torch.manual_seed(args.seed)
+    np.random.seed(args.seed)
+    cfg = Config.fromfile(args.config)
+    if not dist.is_initialized():
+        dist.init_process_group(backend=args.dist_backend, init_method=args.dist_url, rank=rank, world_size=world)
+    model = build_model(args, cfg, rank, device).to(device)
+    if not args.no_channels_last:
+        model.encoder_q.to(memory_format=torch.channels_last)
+        model.encoder_k.to(memory_format=torch.channels_last)
+    use_graph = args.graph and world == 1
+    wrapped = model
+    if world > 1:
+        # queue / BN buffers are updated identically on every rank, so the per-forward buffer
+        # broadcast of the reference's default DDP is dropped; conv_seg is frozen, so
+        # no unused-parameter search is needed either.
+        wrapped = DistributedDataParallel(model, device_ids=[local], output_device=local, broadcast_buffers=False,
+                                          gradient_as_bucket_view=True)
+    optimizer = make_optimizer([p for p in model.parameters()], args, device, capturable=use_graph)
+    if args.resume and os.path.isfile(args.resume):
+        ck = torch.load(args.resume, map_location=device)
+        args.start_epoch = ck["epoch"]
+        wrapped.load_state_dict(ck["state_dict"]) if world > 1 else model.load_state_dict(
+            {k.replace("module.", "", 1): v for k, v in ck["state_dict"].items()})
+        optimizer.load_state_dict(ck["optimizer"])
+    if not args.synthetic:
+        raise NotImplementedError("only --synthetic input is built in; real-image augmentation (reference loader.py) "
+                                  "is a 'next' row of the scope table (SURVEY 8f-1)")
+    per_gpu = args.batch_size // world
+    runner = TrainStep(wrapped, optimizer, use_graph=use_graph)
+    step = 0
+    for epoch in range(args.start_epoch, args.epochs):
+        lr = args.lr if args.remove_lr_scheduler else adjust_learning_rate(optimizer, epoch, args)
+        model.train()
+        t0, seen = time.time(), 0
+        for i in range(args.steps_per_epoch):
+            if step > args.max_steps:
+                break
+            batch = synthetic.make_batch(per_gpu, args.img_height, args.img_width, device,
+                                         seed=args.seed + rank + 1000 * step, foreground_min=args.foreground_min,
+                                         foreground_max=args.foreground_max)
+            if args.same_foreground:
+                batch["img_b"], batch["pixel_ids_b"], batch["region_ids_b"] = batch["img_a"], batch["pixel_ids_a"], batch["region_ids_a"]
+            loss = runner(batch)
+            seen += per_gpu * world
+            if i % args.print_freq == 0 and rank == 0:
+                print(f"Epoch: [{epoch}][{i}/{args.steps_per_epoch}] loss {float(loss):.4f} lr {lr:.5f} "
+                      f"{seen / (time.time() - t0):.0f} img/s", flush=True)
+            step += 1
+        model.on_train_epoch_end(step)
+        last = epoch % args.ckpt_freq == args.ckpt_freq - 1 or step > args.max_steps or epoch >= args.epochs - 1
+        if last and rank == 0:
+            sd = {("module." + k): v for k, v in model.state_dict().items()}    # DDP-prefixed keys (segment_network.py:84-92)
+            save_checkpoint({"epoch": epoch + 1, "state_dict": sd, "optimizer": optimizer.state_dict(),
+                             "pretrain_type": args.pretrain_type.name, "backbone_type": args.backbone_type.name},
+                            epoch=epoch, is_best=True,
+                            filename=os.path.join(args.log_dir, args.run_id, f"{step}_{epoch}_checkpoint.ckpt"))
+        if step > args.max_steps:
+            break
+    dist.destroy_process_group()
+
+
+def main(argv=None):
+    args = get_args(argv)
+    os.makedirs(os.path.join(args.log_dir, args.run_id), exist_ok=True)
+    if args.debug:
+        args.batch_size, args.world_size = 8, 1
+    if "RANK" in os.environ:                                   # torchrun
+        args.world_size = int(os.environ["WORLD_SIZE"])
+        args.dist_url = "env://"
+        main_worker(int(os.environ["RANK"]), args)
+    elif args.world_size == 1:
+        main_worker(0, args)
+    else:
+        mp.spawn(main_worker, nprocs=args.world_size, args=(args,))
+
+
+if __name__ == "__main__":
+    main()

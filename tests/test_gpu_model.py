@@ -1,0 +1,116 @@
+"""GPU: builder.MODEL end to end (BASELINE config 1 shapes: ResNet-18, 64x64 crops, queue 1024)
+against the CPU oracle, eager vs hipGraph step equivalence, and the DenseCL path."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cp2_amd import builder, synthetic
+from cp2_amd.config import Config
+from cp2_amd.engine import TrainStep
+from cp2_amd.main import make_optimizer
+from cp2_amd.pretrain_types import PretrainType
+from oracle import cp2_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def small_model(K=1024, pretrain_type=PretrainType.CP2, cfg_name="config_pretrain_r18.py", **kw):
+    torch.manual_seed(0)
+    cfg = Config.fromfile(os.path.join(ROOT, "configs", cfg_name))
+    extra = dict(lmbd_cp2_dense_loss=0.5, dense_logits_temp=0.2) if pretrain_type == PretrainType.DENSECL else {}
+    m = builder.MODEL(cfg, rank=0, K=K, pretrain_from_scratch=True, pretrain_type=pretrain_type, device=DEV, **extra, **kw)
+    return m.to(DEV).train()
+
+
+def test_forward_cp2_matches_oracle_on_same_features():
+    model = small_model()
+    assert model.output_stride == 16
+    batch = synthetic.make_batch(8, 64, 64, DEV, seed=3)
+    feats = {}
+    hq = model.encoder_q.register_forward_hook(lambda m, i, o: feats.__setitem__("q", o))
+    hk = model.encoder_k.register_forward_hook(lambda m, i, o: feats.__setitem__("k", (i[0], o)))
+    queue0, ptr0 = model.queue.clone(), int(model.queue_ptr)
+    pk0 = [p.detach().clone() for p in model.encoder_k.parameters()]
+    pq0 = [p.detach().clone() for p in model.encoder_q.parameters()]
+    perm = torch.randperm(8)
+    loss = model(visualize=False, step=0, new_epoch=False, idx_shuffle=perm.to(DEV), **batch)
+    loss.backward()
+    hq.remove(), hk.remove()
+    # EMA happened before the key forward, bit-exact
+    want_k = O.momentum_update([p.cpu() for p in pk0], [p.cpu() for p in pq0], 0.999)
+    for p, w in zip(model.encoder_k.parameters(), want_k):
+        assert torch.equal(p.detach().cpu(), w)
+    # the key encoder saw the composed + shuffled batch (bit-exact composition and row gather)
+    want_img_b, _ = O.compose_mask(batch["img_b"].cpu(), batch["bg1"].cpu())
+    assert torch.equal(feats["k"][0].cpu(), O.shuffle_take(want_img_b, perm, 0, 1))
+    # loss section from the very same encoder outputs
+    q_feat = feats["q"].detach().cpu().requires_grad_(True)
+    k_feat = O.unshuffle_take(feats["k"][1].detach().cpu(), perm, 0, 1)
+    r = O.cp2_loss_section(q_feat, k_feat, batch["bg0"].cpu(), batch["bg1"].cpu(), batch["pixel_ids_a"].cpu(),
+                           batch["pixel_ids_b"].cpu(), batch["region_ids_a"].cpu(), batch["region_ids_b"].cpu(),
+                           queue0.cpu(), output_stride=16)
+    assert abs(float(loss) - float(r["loss"])) <= 2e-5
+    # queue update with k_pos, pointer advanced on the device
+    qa, ptr = O.dequeue_and_enqueue(queue0.cpu(), ptr0, r["k_pos"].detach())
+    assert int(model.queue_ptr) == ptr
+    assert (model.queue.cpu() - qa).abs().max() <= 2e-6
+    ious, ious_m = model.epoch_ious()
+    assert np.array_equal(np.float32(ious), r["iou"].numpy()) and np.array_equal(np.float32(ious_m), r["iou_masked"].numpy())
+    logs = model.flush_logs()
+    assert abs(logs[0][1]["train/loss_ins_step"] - float(r["loss_instance"])) <= 2e-5
+    assert abs(logs[0][1]["train/loss_dense_step"] - float(r["loss_dense"])) <= 2e-5
+
+
+def test_state_dict_contract():
+    model = small_model()
+    keys = set(model.state_dict().keys())
+    for k in ("queue", "queue_ptr", "queue2", "queue2_ptr", "encoder_q.backbone.conv1.weight", "encoder_q.backbone.bn1.weight",
+              "encoder_k.backbone.layer4.1.conv2.weight", "encoder_q.decode_head.contrast_conv.0.weight",
+              "encoder_q.decode_head.contrast_conv.2.bias", "encoder_q.decode_head.conv_seg.weight"):
+        assert k in keys, k
+    assert model.queue.shape == (128, 1024) and model.queue_ptr.dtype == torch.long
+    model._momentum_update_key_encoder()                 # flattening must not change the state dict
+    sd = model.state_dict()
+    assert set(sd.keys()) == keys
+    for n, p in model.named_parameters():
+        assert torch.equal(sd[n], p.detach())
+
+
+def test_graph_step_equals_eager_step():
+    """Whole-step hipGraph replay reproduces the eager step (same inputs, same permutations)."""
+    losses = {}
+    for mode in (False, True):
+        model = small_model()
+
+        class A:
+            lr, momentum, weight_decay, optim = 0.03, 0.9, 1e-4, "sgd"
+        opt = make_optimizer(list(model.parameters()), A, DEV, capturable=True)
+        runner = TrainStep(model, opt, use_graph=mode, warmup_steps=2)
+        torch.manual_seed(123)                           # shuffle permutations come from the global host RNG
+        out = []
+        for i in range(6):
+            out.append(float(runner(synthetic.make_batch(8, 64, 64, DEV, seed=i))))
+        losses[mode] = out
+        assert int(model.queue_ptr) == 48
+    assert np.allclose(losses[False], losses[True], rtol=0, atol=5e-4), (losses[False], losses[True])
+    assert losses[False][-1] == losses[False][-1]
+
+
+def test_densecl_forward_backward_runs_and_matches_oracle_losses():
+    model = small_model(K=512, pretrain_type=PretrainType.DENSECL, cfg_name="config_moco.py")
+    batch = synthetic.make_batch(4, 64, 64, DEV, seed=5)
+    q2_before = model.queue2.clone()
+    loss = model(visualize=False, step=0, new_epoch=False, **batch)
+    loss.backward()
+    assert torch.isfinite(loss)
+    g = [p.grad for p in model.encoder_q.parameters() if p.grad is not None]
+    assert len(g) > 100 and all(torch.isfinite(x).all() for x in g)
+    assert int(model.queue_ptr) == 4 and int(model.queue2_ptr) == 4
+    assert not torch.equal(model.queue2, q2_before)
+    logs = model.flush_logs()[0][1]
+    assert abs(0.5 * logs["train/loss_ins_step"] + 0.5 * logs["train/loss_dense_step"] - logs["train/loss_step"]) < 1e-5
