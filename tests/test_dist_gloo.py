@@ -1,0 +1,78 @@
+"""CPU, world size 2 over gloo: the collective plumbing of the hot path (reference builder.py:609-649,
+569-587, 1710-1722).  The device kernels are not involved (they have no CPU path); the row gathers and the
+enqueue are played by the oracle so the multi-rank index logic is checked end to end."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cp2_amd import dist as cdist
+from oracle import cp2_oracle as O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        b = 3
+        torch.manual_seed(100 + rank)                       # ranks deliberately hold different RNG states
+        x = torch.arange(b * 4, dtype=torch.float32).reshape(b, 4) + 1000 * rank
+        # concat_all_gather: rank order on dim 0, no grad
+        g = cdist.concat_all_gather(x.clone().requires_grad_(True))
+        assert g.shape == (world * b, 4) and not g.requires_grad
+        for r in range(world):
+            assert torch.equal(g[r * b:(r + 1) * b], torch.arange(b * 4, dtype=torch.float32).reshape(b, 4) + 1000 * r)
+        # shuffle index: every rank ends up with rank 0's permutation
+        idx = cdist.make_shuffle_index(world * b, "cpu")
+        ref = idx.clone()
+        dist.broadcast(ref, src=0)
+        assert torch.equal(idx, ref) and sorted(idx.tolist()) == list(range(world * b))
+        # shuffle -> per-sample "encoder" -> unshuffle restores this rank's own samples, in order
+        taken = O.shuffle_take(g, idx, rank, world)
+        assert torch.equal(taken, g[cdist.shuffle_rows_for_rank(idx, rank, world)])
+        enc = taken * 2.0 + 1.0
+        enc_all = cdist.concat_all_gather(enc)
+        idx_un, rows = cdist.unshuffle_rows_for_rank(idx, rank, world)
+        restored = enc_all[rows]
+        assert torch.equal(restored, x * 2.0 + 1.0)
+        assert torch.equal(restored, O.unshuffle_take(enc_all, idx, rank, world))
+        # enqueue: every rank appends ALL ranks' keys in rank order -> replicas of the queue stay identical
+        K, C = 8, 4
+        queue = torch.zeros(C, K)
+        ptr = 5                                            # crosses the wrap boundary with 6 keys
+        queue, ptr = O.dequeue_and_enqueue(queue, ptr, cdist.concat_all_gather(x))
+        assert ptr == (5 + world * b) % K
+        torch.save(queue, os.path.join(out_dir, f"q{rank}.pt"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_world2_gloo_collectives(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    q0, q1 = torch.load(tmp_path / "q0.pt"), torch.load(tmp_path / "q1.pt")
+    assert torch.equal(q0, q1)
+    want = torch.cat([torch.arange(12, dtype=torch.float32).reshape(3, 4) + 1000 * r for r in range(world)])
+    cols = [(5 + i) % 8 for i in range(6)]
+    assert torch.equal(q0[:, cols], want.t())
+
+
+def test_single_process_helpers_without_process_group():
+    x = torch.randn(4, 3)
+    assert cdist.world_size() == 1 and cdist.rank() == 0
+    assert cdist.concat_all_gather(x) is x
+    idx = cdist.make_shuffle_index(8, "cpu", generator=torch.Generator().manual_seed(1))
+    assert sorted(idx.tolist()) == list(range(8))
