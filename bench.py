@@ -106,13 +106,14 @@ def main():
     model.ema_in_forward = False
     ema_events = []
 
+    from cp2_amd.hipevents import EventPair
+    model.flatten_parameters()
+
     def one_step(i, timed):
         if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            model._momentum_update_key_encoder()
-            e1.record()
-            ema_events.append((e0, e1))
+            ev = EventPair()                                  # hipEvent_t pair attached to the kernel launch itself
+            ops.ema_flat_timed(model._flat_k, model._flat_q, model.momentum, ev)
+            ema_events.append(ev)
         else:
             model._momentum_update_key_encoder()
         return runner(batches[i % len(batches)])
@@ -139,7 +140,7 @@ def main():
     loss_val = float(loss)
     assert loss_val == loss_val, "loss is NaN"
 
-    ema_ms = sum(a.elapsed_time(bb) for a, bb in ema_events) / len(ema_events)
+    ema_ms = sum(ev.elapsed_ms() for ev in ema_events) / len(ema_events)
     n_param_floats = model._flat_q.numel()
     ema_bytes = 12 * n_param_floats                      # read k, read q, write k: 12 algorithmic bytes per parameter slot
     achieved = ema_bytes / (ema_ms * 1e-3) / 1e9

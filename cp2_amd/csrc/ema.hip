@@ -4,6 +4,7 @@
 //   bit-identical to the reference.  HBM-bound: 12 algorithmic bytes per element
 //   (read k, read q, write k).  One launch for the whole encoder.
 #include "common.hpp"
+#include <hip/hip_ext.h>
 
 __device__ __forceinline__ float ema1(float k, float q, float m, float om) {
     return __fadd_rn(__fmul_rn(k, m), __fmul_rn(q, om));
@@ -13,48 +14,56 @@ __device__ __forceinline__ float4 ema4(float4 k, float4 q, float m, float om) {
                        ema1(k.w, q.w, m, om));
 }
 
-// Flat span: each block owns UNROLL*256 consecutive float4; all loads of an
-// iteration are issued before the first store so 2*UNROLL 16-byte loads per lane
-// are in flight.
-template <int UNROLL>
-__global__ __launch_bounds__(256) void ema_flat_kernel(float* __restrict__ k, const float* __restrict__ q,
-                                                       int64_t n4, int64_t n, float m, float om) {
-    float4* k4 = reinterpret_cast<float4*>(k);
-    const float4* q4 = reinterpret_cast<const float4*>(q);
-    const int64_t span = (int64_t)blockDim.x * UNROLL;
-    for (int64_t base = (int64_t)blockIdx.x * span; base < n4; base += (int64_t)gridDim.x * span) {
-        float4 kv[UNROLL], qv[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const int64_t i = base + threadIdx.x + (int64_t)u * blockDim.x;
-            if (i < n4) {
-                kv[u] = k4[i];
-                qv[u] = q4[i];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const int64_t i = base + threadIdx.x + (int64_t)u * blockDim.x;
-            if (i < n4) k4[i] = ema4(kv[u], qv[u], m, om);
-        }
+// Flat span, tuned on MI355X (scratch/ema_tune*.hip, kernel-exact events, infinity cache flushed
+// between launches): 128-thread workgroups, ONE 16-byte element per lane, exact grid, and
+// non-temporal loads/stores (every byte is touched once per step, so nothing should linger in
+// L2 / MALL) reached 6.4-6.5 TB/s = 81 % of the 8 TB/s HBM3E peak; 256 threads x 4 elements
+// with plain loads (the first version) 4.5 TB/s.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr int kEmaThreads = 128;
+
+__global__ __launch_bounds__(kEmaThreads) void ema_flat_kernel(float* __restrict__ k, const float* __restrict__ q,
+                                                               int64_t n4, int64_t n, float m, float om) {
+    const int64_t i = (int64_t)blockIdx.x * kEmaThreads + threadIdx.x;
+    if (i < n4) {
+        f32x4_t* k4 = reinterpret_cast<f32x4_t*>(k);
+        const f32x4_t* q4 = reinterpret_cast<const f32x4_t*>(q);
+        const f32x4_t kv = __builtin_nontemporal_load(k4 + i);
+        const f32x4_t qv = __builtin_nontemporal_load(q4 + i);
+        f32x4_t r;
+        r.x = ema1(kv.x, qv.x, m, om); r.y = ema1(kv.y, qv.y, m, om);
+        r.z = ema1(kv.z, qv.z, m, om); r.w = ema1(kv.w, qv.w, m, om);
+        __builtin_nontemporal_store(r, k4 + i);
     }
-    // tail (n not a multiple of 4)
-    if (blockIdx.x == 0) {
-        for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) k[i] = ema1(k[i], q[i], m, om);
+    if (blockIdx.x == 0) {  // tail (n not a multiple of 4)
+        for (int64_t j = n4 * 4 + threadIdx.x; j < n; j += kEmaThreads) k[j] = ema1(k[j], q[j], m, om);
     }
 }
 
-CP2_API int cp2_ema_flat(float* k, const float* q, int64_t n, float m, float one_minus_m, void* stream) {
+static int ema_flat_launch(float* k, const float* q, int64_t n, float m, float one_minus_m, hipEvent_t start,
+                           hipEvent_t stop, void* stream) {
     if (!k || !q) return CP2_ERR_NULL;
     if (n <= 0) return CP2_ERR_SHAPE;
     if (!cp2_aligned16(k) || !cp2_aligned16(q)) return CP2_ERR_ALIGN;
-    constexpr int UNROLL = 4;
     const int64_t n4 = n / 4;
-    int blocks = cp2_cdiv(n4 > 0 ? n4 : 1, 256 * UNROLL);
-    if (blocks > 256 * 16) blocks = 256 * 16;  // 16 workgroups per CU, grid-stride beyond
-    hipLaunchKernelGGL(ema_flat_kernel<UNROLL>, dim3(blocks), dim3(256), 0, cp2_stream(stream), k, q, n4, n, m,
-                       one_minus_m);
+    const int64_t blocks = n4 > 0 ? (n4 + kEmaThreads - 1) / kEmaThreads : 1;
+    if (blocks > 0x7fffffffLL) return CP2_ERR_UNSUPPORTED;
+    hipExtLaunchKernelGGL(ema_flat_kernel, dim3((unsigned)blocks), dim3(kEmaThreads), 0, cp2_stream(stream), start, stop,
+                          0, k, q, n4, n, m, one_minus_m);
     return cp2_launch_status();
+}
+
+CP2_API int cp2_ema_flat(float* k, const float* q, int64_t n, float m, float one_minus_m, void* stream) {
+    return ema_flat_launch(k, q, n, m, one_minus_m, nullptr, nullptr, stream);
+}
+
+// Same launch with a pair of caller-owned hipEvent_t that bracket exactly this kernel
+// (hipExtLaunchKernelGGL start/stop events): used by bench.py for the roofline figure.
+CP2_API int cp2_ema_flat_timed(float* k, const float* q, int64_t n, float m, float one_minus_m, void* start_event,
+                               void* stop_event, void* stream) {
+    if (!start_event || !stop_event) return CP2_ERR_NULL;
+    return ema_flat_launch(k, q, n, m, one_minus_m, reinterpret_cast<hipEvent_t>(start_event),
+                           reinterpret_cast<hipEvent_t>(stop_event), stream);
 }
 
 // Multi-tensor form: block c handles chunk c = (tensor, offset, length).

@@ -31,16 +31,51 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 }
 
 // LDS tile T[c][j], j < KT, row pitch KT+1 floats (odd pitch: both the row read of
-// product 1 and the column read of product 2 are bank-conflict free).
+// product 1 and the column read of product 2 are bank-conflict free).  The fill is split
+// in two so the global loads of the NEXT tile are in flight while the current one is used:
+// tile_load (global -> registers, 16 bytes per lane when aligned) ... tile_store (-> LDS).
+template <int KT>
+struct TileRegs {
+    float4 v[CH * KT / 1024];
+};
+
+template <int KT>
+__device__ __forceinline__ void tile_load(TileRegs<KT>& rg, const float* __restrict__ src, int64_t ld, int j0, int jmax,
+                                          int tid, bool vec_ok) {
+    constexpr int Q = KT / 4;  // float4 per tile row
+#pragma unroll
+    for (int i = 0; i < CH * KT / 1024; ++i) {
+        const int e = tid + i * 256, c = e / Q, j = (e % Q) * 4;
+        const float* p = src + (int64_t)c * ld + j0 + j;
+        if (vec_ok && j0 + j + 3 < jmax) {
+            rg.v[i] = *reinterpret_cast<const float4*>(p);
+        } else {
+            rg.v[i].x = (j0 + j + 0 < jmax) ? p[0] : 0.f;
+            rg.v[i].y = (j0 + j + 1 < jmax) ? p[1] : 0.f;
+            rg.v[i].z = (j0 + j + 2 < jmax) ? p[2] : 0.f;
+            rg.v[i].w = (j0 + j + 3 < jmax) ? p[3] : 0.f;
+        }
+    }
+}
+
+template <int KT>
+__device__ __forceinline__ void tile_store(float* __restrict__ T, const TileRegs<KT>& rg, int tid) {
+    constexpr int Q = KT / 4, KP = KT + 1;
+#pragma unroll
+    for (int i = 0; i < CH * KT / 1024; ++i) {
+        const int e = tid + i * 256, c = e / Q, j = (e % Q) * 4;
+        float* d = T + c * KP + j;
+        d[0] = rg.v[i].x; d[1] = rg.v[i].y; d[2] = rg.v[i].z; d[3] = rg.v[i].w;
+    }
+}
+
 template <int KT>
 __device__ __forceinline__ void fill_tile(float* __restrict__ T, const float* __restrict__ src, int64_t ld, int j0,
                                           int jmax, int tid) {
-    constexpr int KP = KT + 1;
-#pragma unroll 4
-    for (int e = tid; e < CH * KT; e += 256) {
-        const int c = e / KT, j = e % KT;
-        T[c * KP + j] = (j0 + j < jmax) ? src[(int64_t)c * ld + j0 + j] : 0.f;
-    }
+    TileRegs<KT> rg;
+    const bool vec_ok = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) && (j0 % 4 == 0);
+    tile_load<KT>(rg, src, ld, j0, jmax, tid, vec_ok);
+    tile_store<KT>(T, rg, tid);
 }
 
 // S^T[other = kk + rho(reg,h)][owner = lane&31] for one 32x32 sub-tile.
@@ -99,10 +134,14 @@ __global__ __launch_bounds__(256) void rowkey_fwd_kernel(RowKeyArgs a) {
     for (int cb = 0; cb < 4; ++cb) U[cb] = (f32x16){0};
     const int k_begin = blockIdx.y * a.keys_per_split;
     const int k_end = min(a.K, k_begin + a.keys_per_split);
+    const bool vec_ok = (a.K % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.keys) & 15u) == 0);
+    TileRegs<KT> rg;
+    tile_load<KT>(rg, a.keys, a.K, k_begin, k_end, tid, vec_ok);
     for (int k0 = k_begin; k0 < k_end; k0 += KT) {
         __syncthreads();
-        fill_tile<KT>(T, a.keys, a.K, k0, k_end, tid);
+        tile_store<KT>(T, rg, tid);
         __syncthreads();
+        if (k0 + KT < k_end) tile_load<KT>(rg, a.keys, a.K, k0 + KT, k_end, tid, vec_ok);  // next tile, in flight during the MFMAs
 #pragma unroll
         for (int s = 0; s < NSUB; ++s) {
             const int kk = (wk + WK * s) * 32;
@@ -216,6 +255,8 @@ struct RowKeyFinArgs {
     float* lse; float* loss_rows; int* cnt_gt; float* drows; float* dE;
 };
 
+constexpr int FIN_CPW = 4;  // channels per wave in the finalize kernel: grid.y = CH / (4 * FIN_CPW) channel groups
+
 __global__ __launch_bounds__(256) void rowkey_finalize_kernel(RowKeyFinArgs a) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int row = blockIdx.x * 64 + lane;
@@ -225,16 +266,16 @@ __global__ __launch_bounds__(256) void rowkey_finalize_kernel(RowKeyFinArgs a) {
     float e[4] = {0.f, 0.f, 0.f, 0.f};
     for (int j = 0; j < a.NE; ++j) { e[j] = a.extras[(int64_t)row * a.NE + j] * a.inv_t; M = fmaxf(M, e[j]); }
     float Z = 0.f;
-    int cnt = 0;
     for (int s = 0; s < a.S; ++s) {
         const float ms = a.part_m[(int64_t)s * a.R + row];
         if (ms != -INFINITY) Z += a.part_s[(int64_t)s * a.R + row] * expf(ms - M);
-        cnt += a.part_cnt[(int64_t)s * a.R + row];
     }
     for (int j = 0; j < a.NE; ++j) Z += expf(e[j] - M);
-    for (int j = 1; j < a.NE; ++j) cnt += (e[j] > e[0]) ? 1 : 0;  // extra negatives also rank against the positive
     const float lse = M + logf(Z);
-    if (w == 0) {
+    if (w == 0 && blockIdx.y == 0) {
+        int cnt = 0;
+        for (int s = 0; s < a.S; ++s) cnt += a.part_cnt[(int64_t)s * a.R + row];
+        for (int j = 1; j < a.NE; ++j) cnt += (e[j] > e[0]) ? 1 : 0;  // extra negatives also rank against the positive
         a.lse[row] = lse;
         a.loss_rows[row] = lse - e[0];
         a.cnt_gt[row] = cnt;
@@ -243,21 +284,22 @@ __global__ __launch_bounds__(256) void rowkey_finalize_kernel(RowKeyFinArgs a) {
                 a.dE[(int64_t)row * a.NE + j] = a.grad_scale * a.inv_t * (expf(e[j] - lse) - (j == 0 ? 1.f : 0.f));
     }
     if (!a.drows) return;
-    float acc[CH / 4];
+    const int c0 = (blockIdx.y * 4 + w) * FIN_CPW;
+    float acc[FIN_CPW];
 #pragma unroll
-    for (int i = 0; i < CH / 4; ++i) acc[i] = 0.f;
+    for (int i = 0; i < FIN_CPW; ++i) acc[i] = 0.f;
+#pragma unroll 4
     for (int s = 0; s < a.S; ++s) {
         const float ms = a.part_m[(int64_t)s * a.R + row];
-        if (ms == -INFINITY) continue;
-        const float ws = expf(ms - lse);
-        const float* u = a.part_U + ((int64_t)s * CH + w * (CH / 4)) * a.R + row;
+        const float ws = (ms == -INFINITY) ? 0.f : expf(ms - lse);
+        const float* u = a.part_U + ((int64_t)s * CH + c0) * a.R + row;
 #pragma unroll
-        for (int i = 0; i < CH / 4; ++i) acc[i] += u[(int64_t)i * a.R] * ws;
+        for (int i = 0; i < FIN_CPW; ++i) acc[i] += u[(int64_t)i * a.R] * ws;
     }
     float* d = a.drows + (int64_t)(row / a.RP) * a.d_sn + (int64_t)(row % a.RP) * a.d_sx;
     const float gs = a.grad_scale * a.inv_t;
 #pragma unroll
-    for (int i = 0; i < CH / 4; ++i) d[(int64_t)(w * (CH / 4) + i) * a.d_sc] = acc[i] * gs;
+    for (int i = 0; i < FIN_CPW; ++i) d[(int64_t)(c0 + i) * a.d_sc] = acc[i] * gs;
 }
 
 // out[0] = mean(x[0..n)) (single workgroup: deterministic order)
@@ -279,14 +321,14 @@ static int rowkey_shape(int R, int* WR, int* WK) {
 }
 
 CP2_API int cp2_rowkey_num_splits(int R, int K) {
-    // enough workgroups to fill 256 CUs about twice over, at least 4 LDS tiles of keys per split
+    // enough workgroups to fill 256 CUs about twice over, at least 2 LDS tiles of keys per split
     if (R <= 0 || K <= 0) return CP2_ERR_SHAPE;
     int WR, WK;
     rowkey_shape(R, &WR, &WK);
     const int KT = 32 * WK * (WK == 1 ? 2 : 1);
     const int row_blocks = cp2_cdiv(R, 32 * WR);
     int ns = cp2_cdiv(512, row_blocks);
-    const int max_ns = cp2_cdiv(K, 4 * KT);
+    const int max_ns = cp2_cdiv(K, 2 * KT);
     if (ns > max_ns) ns = max_ns;
     if (ns < 1) ns = 1;
     return ns;
@@ -342,7 +384,8 @@ CP2_API int cp2_rowkey_infonce_finalize(const float* part_m, const float* part_s
     if (C != CH) return CP2_ERR_UNSUPPORTED;
     RowKeyFinArgs a{part_m, part_s, part_cnt, part_U, nsplit, extras, NE, 1.0f / temperature, grad_scale,
                     R, RP, d_sn, d_sx, d_sc, lse, loss_rows, cnt_gt, drows, dE};
-    hipLaunchKernelGGL(rowkey_finalize_kernel, dim3(cp2_cdiv(R, 64)), dim3(256), 0, cp2_stream(stream), a);
+    hipLaunchKernelGGL(rowkey_finalize_kernel, dim3(cp2_cdiv(R, 64), drows ? CH / (4 * FIN_CPW) : 1), dim3(256), 0,
+                       cp2_stream(stream), a);
     int rc = cp2_launch_status();
     if (rc || !loss_mean) return rc;
     hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, cp2_stream(stream), loss_rows, R, loss_mean);

@@ -122,6 +122,15 @@ def ema_flat(k: torch.Tensor, q: torch.Tensor, m: float) -> None:
     _lib.check(rc, "cp2_ema_flat")
 
 
+def ema_flat_timed(k: torch.Tensor, q: torch.Tensor, m: float, events) -> None:
+    """ema_flat with an `hipevents.EventPair` bracketing exactly this kernel."""
+    lib = _lib.load()
+    m32, om32 = ema_scalars(m)
+    rc = lib.cp2_ema_flat_timed(_dev(k, "k", torch.float32), _dev(q, "q", torch.float32), k.numel(), m32, om32,
+                                events.start, events.stop, _stream())
+    _lib.check(rc, "cp2_ema_flat_timed")
+
+
 class EmaMultiPlan:
     """Device tables for cp2_ema_multi over two parameter lists (built once, reused every step)."""
 

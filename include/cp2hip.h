@@ -71,6 +71,10 @@ int cp2_corr_iou(const int64_t* ids_a, const int64_t* ids_b, const float* mask_a
  * k[i] = k[i]*m + q[i]*one_minus_m  (two rounded products, one rounded sum; no FMA).
  * Flat form: one contiguous span of n floats (16-byte aligned). */
 int cp2_ema_flat(float* k, const float* q, int64_t n, float m, float one_minus_m, void* stream);
+/* Same launch; start_event / stop_event are caller-owned hipEvent_t that bracket exactly this kernel
+ * (for hipEventElapsedTime after the stream has been synchronised). */
+int cp2_ema_flat_timed(float* k, const float* q, int64_t n, float m, float one_minus_m, void* start_event,
+                       void* stop_event, void* stream);
 /* Multi-tensor form: device tables of n_tensors pointers/sizes, plus a device chunk
  * table built by the caller: chunk c covers elements [chunk_off[c], chunk_off[c]+chunk_len[c])
  * of tensor chunk_tensor[c].  One launch for the whole encoder. */
