@@ -39,6 +39,8 @@ def parse():
     p.add_argument("--amp", default="bf16", choices=["bf16", "none"])
     p.add_argument("--graph", default="auto", choices=["auto", "on", "off"], help="whole-step hipGraph (auto: on at N=1)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
+    p.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     p.add_argument("--cpu-batch", type=int, default=8)
     p.add_argument("--cpu-steps", type=int, default=2)
     return p.parse_args()
@@ -67,10 +69,12 @@ def main():
             raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if args.one_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from cp2_amd import builder, ops, synthetic
     from cp2_amd.config import Config

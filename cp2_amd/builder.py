@@ -246,10 +246,15 @@ class MODEL(nn.Module):
         flat_k = torch.zeros(total, dtype=torch.float32, device=dev)
         for p, k, o in zip(pq, pk, offs):
             assert p.dtype == torch.float32 and k.shape == p.shape
-            flat_q[o:o + p.numel()].copy_(p.data.reshape(-1))
-            flat_k[o:o + p.numel()].copy_(k.data.reshape(-1))
-            p.data = flat_q[o:o + p.numel()].view(p.shape)
-            k.data = flat_k[o:o + p.numel()].view(p.shape)
+            if k.stride() != p.stride():
+                k.data = k.data.clone(memory_format=torch.preserve_format).as_strided(p.shape, p.stride()).copy_(k.data)
+            # keep each parameter's own dense layout (e.g. channels-last conv weights) inside its slot: the slot
+            # holds the elements in PHYSICAL order, the same order in both encoders, so the EMA stays elementwise
+            vq = torch.as_strided(flat_q, p.shape, p.stride(), o)
+            vk = torch.as_strided(flat_k, p.shape, p.stride(), o)
+            vq.copy_(p.data)
+            vk.copy_(k.data)
+            p.data, k.data = vq, vk
         self._flat_q, self._flat_k, self._flat_offsets = flat_q, flat_k, offs
 
     @torch.no_grad()

@@ -30,7 +30,10 @@ def concat_all_gather(tensor: torch.Tensor) -> torch.Tensor:
     tensor = tensor.contiguous()
     out = torch.empty((world_size() * tensor.shape[0],) + tuple(tensor.shape[1:]), dtype=tensor.dtype,
                       device=tensor.device)
-    dist.all_gather_into_tensor(out, tensor)
+    if dist.get_backend() == "gloo" and tensor.is_cuda:      # rehearsal only: gloo has no fused all-gather for GPU tensors
+        dist.all_gather(list(out.chunk(world_size(), dim=0)), tensor)
+    else:
+        dist.all_gather_into_tensor(out, tensor)
     return out
 
 

@@ -117,3 +117,25 @@ def test_densecl_forward_backward_runs_and_matches_oracle_losses():
     assert not torch.equal(model.queue2, q2_before)
     logs = model.flush_logs()[0][1]
     assert abs(0.5 * logs["train/loss_ins_step"] + 0.5 * logs["train/loss_dense_step"] - logs["train/loss_step"]) < 1e-5
+
+
+def test_flatten_preserves_channels_last_and_values():
+    model = small_model()
+    model.encoder_q.to(memory_format=torch.channels_last)
+    model.encoder_k.to(memory_format=torch.channels_last)
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    strides = {n: p.stride() for n, p in model.named_parameters()}
+    model.flatten_parameters()
+    for n, p in model.named_parameters():
+        assert p.stride() == strides[n], n
+        assert torch.equal(p.detach(), before[n]), n
+    w = model.encoder_q.backbone.layer2[0].conv2.weight
+    assert w.is_contiguous(memory_format=torch.channels_last) and not w.is_contiguous()
+    # EMA over the flat buffers == per-parameter EMA
+    for p in model.encoder_q.parameters():
+        p.data.add_(0.01)
+    want = O.momentum_update([p.detach().cpu() for p in model.encoder_k.parameters()],
+                             [p.detach().cpu() for p in model.encoder_q.parameters()], 0.999)
+    model._momentum_update_key_encoder()
+    for p, w_ in zip(model.encoder_k.parameters(), want):
+        assert torch.equal(p.detach().cpu(), w_)
