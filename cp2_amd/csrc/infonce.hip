@@ -302,6 +302,78 @@ __global__ __launch_bounds__(256) void rowkey_finalize_kernel(RowKeyFinArgs a) {
     for (int i = 0; i < FIN_CPW; ++i) d[(int64_t)(c0 + i) * a.d_sc] = acc[i] * gs;
 }
 
+// Many-splits form (instance loss: R = batch size, S = 256 splits): a serial loop over S per row is pure
+// load latency (measured 204-236 us), so here 8 "split lanes" share each row: thread = (row r of 32, lane sl of 8),
+// each lane reduces the splits s = sl, sl+8, ... and the 8 partial results meet in LDS.  grid = (R/32, CH/8).
+constexpr int FS_SL = 8, FS_CPB = 8;
+
+__global__ __launch_bounds__(256) void rowkey_finalize_spar_kernel(RowKeyFinArgs a) {
+    __shared__ float red[FS_SL][32];
+    __shared__ int redi[FS_SL][32];
+    __shared__ float red2[FS_CPB][FS_SL][32];
+    const int r = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int row = blockIdx.x * 32 + r;
+    const bool ok = row < a.R;
+    const int rr = ok ? row : 0;
+    float M = -INFINITY;
+    for (int s = sl; s < a.S; s += FS_SL) M = fmaxf(M, a.part_m[(int64_t)s * a.R + rr]);
+    red[sl][r] = M;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < FS_SL; ++j) M = fmaxf(M, red[j][r]);
+    float e[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < a.NE; ++j) { e[j] = a.extras[(int64_t)rr * a.NE + j] * a.inv_t; M = fmaxf(M, e[j]); }
+    __syncthreads();
+    float z = 0.f;
+    int cnt = 0;
+    for (int s = sl; s < a.S; s += FS_SL) {
+        const float ms = a.part_m[(int64_t)s * a.R + rr];
+        if (ms != -INFINITY) z += a.part_s[(int64_t)s * a.R + rr] * expf(ms - M);
+        cnt += a.part_cnt[(int64_t)s * a.R + rr];
+    }
+    red[sl][r] = z;
+    redi[sl][r] = cnt;
+    __syncthreads();
+    float Z = 0.f;
+    cnt = 0;
+#pragma unroll
+    for (int j = 0; j < FS_SL; ++j) { Z += red[j][r]; cnt += redi[j][r]; }
+    for (int j = 0; j < a.NE; ++j) Z += expf(e[j] - M);
+    for (int j = 1; j < a.NE; ++j) cnt += (e[j] > e[0]) ? 1 : 0;
+    const float lse = M + logf(Z);
+    if (sl == 0 && blockIdx.y == 0 && ok) {
+        a.lse[row] = lse;
+        a.loss_rows[row] = lse - e[0];
+        a.cnt_gt[row] = cnt;
+        if (a.dE)
+            for (int j = 0; j < a.NE; ++j)
+                a.dE[(int64_t)row * a.NE + j] = a.grad_scale * a.inv_t * (expf(e[j] - lse) - (j == 0 ? 1.f : 0.f));
+    }
+    if (!a.drows) return;
+    const int c0 = blockIdx.y * FS_CPB;
+    float acc[FS_CPB];
+#pragma unroll
+    for (int i = 0; i < FS_CPB; ++i) acc[i] = 0.f;
+#pragma unroll 2
+    for (int s = sl; s < a.S; s += FS_SL) {
+        const float ms = a.part_m[(int64_t)s * a.R + rr];
+        const float ws = (ms == -INFINITY) ? 0.f : expf(ms - lse);
+        const float* u = a.part_U + ((int64_t)s * CH + c0) * a.R + rr;
+#pragma unroll
+        for (int i = 0; i < FS_CPB; ++i) acc[i] += u[(int64_t)i * a.R] * ws;
+    }
+#pragma unroll
+    for (int i = 0; i < FS_CPB; ++i) red2[i][sl][r] = acc[i];
+    __syncthreads();
+    float tot = 0.f;                       // split lane sl finishes channel c0 + sl
+#pragma unroll
+    for (int j = 0; j < FS_SL; ++j) tot += red2[sl][j][r];
+    if (ok) {
+        float* d = a.drows + (int64_t)(row / a.RP) * a.d_sn + (int64_t)(row % a.RP) * a.d_sx;
+        d[(int64_t)(c0 + sl) * a.d_sc] = tot * a.grad_scale * a.inv_t;
+    }
+}
+
 // out[0] = mean(x[0..n)) (single workgroup: deterministic order)
 __global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
     __shared__ float red[4];
@@ -384,8 +456,12 @@ CP2_API int cp2_rowkey_infonce_finalize(const float* part_m, const float* part_s
     if (C != CH) return CP2_ERR_UNSUPPORTED;
     RowKeyFinArgs a{part_m, part_s, part_cnt, part_U, nsplit, extras, NE, 1.0f / temperature, grad_scale,
                     R, RP, d_sn, d_sx, d_sc, lse, loss_rows, cnt_gt, drows, dE};
-    hipLaunchKernelGGL(rowkey_finalize_kernel, dim3(cp2_cdiv(R, 64), drows ? CH / (4 * FIN_CPW) : 1), dim3(256), 0,
-                       cp2_stream(stream), a);
+    if (nsplit >= 16)
+        hipLaunchKernelGGL(rowkey_finalize_spar_kernel, dim3(cp2_cdiv(R, 32), drows ? CH / FS_CPB : 1), dim3(256), 0,
+                           cp2_stream(stream), a);
+    else
+        hipLaunchKernelGGL(rowkey_finalize_kernel, dim3(cp2_cdiv(R, 64), drows ? CH / (4 * FIN_CPW) : 1), dim3(256), 0,
+                           cp2_stream(stream), a);
     int rc = cp2_launch_status();
     if (rc || !loss_mean) return rc;
     hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, cp2_stream(stream), loss_rows, R, loss_mean);
