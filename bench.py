@@ -46,6 +46,8 @@ def parse():
                         "gradients of four 1x1 convolutions come back as garbage under graph REPLAY (DESIGN.md section 5); "
                         "eager mode is within 2 %% of the graph anyway (the GPU is saturated)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--overlap", default="auto", choices=["auto", "on", "off"],
+                   help="key branch (EMA, shuffle all-gathers, key encoder) on a side HIP stream; auto = when N > 1")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     p.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     p.add_argument("--cpu-batch", type=int, default=8)
@@ -115,6 +117,7 @@ def main():
     # the EMA is hoisted in front of the (graph-captured) rest of the step so each of its launches can be
     # bracketed by HIP events on the launch stream; it reads theta_q after the previous optimizer step and
     # runs before the key encoder, exactly where the reference's call does (builder.py:1272).
+    model.overlap_key_branch = {"auto": None, "on": True, "off": False}[args.overlap]
     model.ema_in_forward = False
     ema_events = []
 

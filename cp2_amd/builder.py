@@ -225,6 +225,8 @@ class MODEL(nn.Module):
         self.correlation_ious, self.masked_correlation_ious = [], []
         self._flat_q = self._flat_k = None
         self.ema_in_forward = True       # False: the caller runs _momentum_update_key_encoder() itself before forward
+        self.overlap_key_branch = None   # key branch on a side stream: None = only when world size > 1 (no gain at N=1)
+        self._side_stream = None
         self._pending_logs = []          # device scalars waiting for one batched device->host copy
         self.sync_logs_every = 0         # 0: only when flush_logs() / on_train_epoch_end() is called
 
@@ -233,11 +235,11 @@ class MODEL(nn.Module):
         """Re-home every encoder parameter into one contiguous fp32 buffer per encoder (same offsets
         in both), so the EMA is a single streaming kernel over 12 bytes per parameter.  Idempotent;
         called lazily by the first forward (after .to(device) / DDP wrapping)."""
+        first = next(self.encoder_q.parameters())
+        if self._flat_q is not None and self._flat_q.device == first.device and first.data_ptr() == self._flat_q.data_ptr():
+            return                                           # already flat (O(1) check, runs every step)
         pq, pk = list(self.encoder_q.parameters()), list(self.encoder_k.parameters())
         dev = pq[0].device
-        if self._flat_q is not None and self._flat_q.device == dev and \
-                all(p.data_ptr() == self._flat_q.data_ptr() + 4 * o for p, o in zip(pq, self._flat_offsets)):
-            return
         offs, total = [], 0
         for p in pq:
             offs.append(total)
@@ -262,6 +264,11 @@ class MODEL(nn.Module):
         """theta_k = theta_k*m + theta_q*(1-m) for every encoder parameter (reference builder.py:557-567)."""
         self.flatten_parameters()
         ops.ema_flat(self._flat_k, self._flat_q, self.momentum)
+
+    def _key_stream(self):
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream()
+        return self._side_stream
 
     # ------------------------------------------------------------------ queue
     @torch.no_grad()
@@ -325,13 +332,24 @@ class MODEL(nn.Module):
         self.correlation_ious.append(iou)
         self.masked_correlation_ious.append(iou_masked)
 
-        q = self._encode(self.encoder_q, img_a).float()                          # queries: b x C x h x w
-        with torch.no_grad():
+        # The key branch (EMA -> shuffle-BN all-gather -> key encoder -> un-shuffle all-gather) does not depend on
+        # the query encoder, so it runs on a side HIP stream: its RCCL all-gathers and small kernels overlap with
+        # the query forward on the main stream (reference order builder.py:1260-1277 is serial).
+        self.flatten_parameters()        # on the main stream, before the fork: it re-homes the query parameters too
+        cur = torch.cuda.current_stream()
+        overlap = cdist.world_size() > 1 if self.overlap_key_branch is None else self.overlap_key_branch
+        side = self._key_stream() if overlap else cur
+        if side is not cur:
+            side.wait_stream(cur)
+        with torch.cuda.stream(side), torch.no_grad():
             if self.ema_in_forward:
                 self._momentum_update_key_encoder()
             img_b, idx_unshuffle = self._batch_shuffle_ddp(img_b, idx_shuffle)
             k = self._encode(self.encoder_k, img_b)
             k = self._batch_unshuffle_ddp(k, idx_unshuffle)
+        q = self._encode(self.encoder_q, img_a).float()                          # queries: b x C x h x w
+        if side is not cur:
+            cur.wait_stream(side)
 
         out = CF.cp2_loss_section(q, k, mask_a, mask_b, self.queue, temp_global=self.temp_global,
                                   temp_local=self.temp_local, lmbd_dense=self.lmbd_dense_loss,
