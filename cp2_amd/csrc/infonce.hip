@@ -79,22 +79,47 @@ __device__ __forceinline__ void fill_tile(float* __restrict__ T, const float* __
 }
 
 // S^T[other = kk + rho(reg,h)][owner = lane&31] for one 32x32 sub-tile.
+// The A operands are read from LDS one group of PF values ahead of the MFMAs that consume them, so the
+// ~100-cycle ds_read latency hides behind the previous group's 64-cycle MFMAs instead of stalling each pair.
+constexpr int PF = 8;
 template <int KP>
 __device__ __forceinline__ f32x16 product1(const float* __restrict__ T, int kk, const float (&bq)[CH / 2], int r, int h) {
     f32x16 acc = {0};
+    const float* p = T + h * KP + kk + r;
+    float cur[PF], nxt[PF];
 #pragma unroll
-    for (int t = 0; t < CH / 2; ++t) acc = mfma32(T[(2 * t + h) * KP + kk + r], bq[t], acc);
+    for (int j = 0; j < PF; ++j) cur[j] = p[(2 * j) * KP];
+#pragma unroll
+    for (int g = 0; g < CH / 2 / PF; ++g) {
+        if (g + 1 < CH / 2 / PF) {
+#pragma unroll
+            for (int j = 0; j < PF; ++j) nxt[j] = p[(2 * ((g + 1) * PF + j)) * KP];
+        }
+#pragma unroll
+        for (int j = 0; j < PF; ++j) acc = mfma32(cur[j], bq[g * PF + j], acc);
+#pragma unroll
+        for (int j = 0; j < PF; ++j) cur[j] = nxt[j];
+    }
     return acc;
 }
 // U^T[c = cb*32 + rho(reg',h)][owner] += sum_other T[c][other] * p[other][owner]
 template <int KP>
 __device__ __forceinline__ void product2(const float* __restrict__ T, int kk, const float (&p)[16], f32x16 (&U)[4], int r,
                                          int h) {
+    const float* base = T + r * KP + kk + 4 * h;
+    float cur[16], nxt[16];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) cur[reg] = base[rho(reg, 0)];
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
+        if (cb + 1 < 4) {
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg)
-            U[cb] = mfma32(T[(cb * 32 + r) * KP + kk + rho(reg, 0) + 4 * h], p[reg], U[cb]);
+            for (int reg = 0; reg < 16; ++reg) nxt[reg] = base[(cb + 1) * 32 * KP + rho(reg, 0)];
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) U[cb] = mfma32(cur[reg], p[reg], U[cb]);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) cur[reg] = nxt[reg];
     }
 }
 
@@ -111,7 +136,9 @@ struct RowKeyArgs {
 };
 
 template <int WR, int WK, bool WITH_U>
-__global__ __launch_bounds__(256) void rowkey_fwd_kernel(RowKeyArgs a) {
+__global__ __launch_bounds__(256, WK == 1 ? 2 : 1) void rowkey_fwd_kernel(RowKeyArgs a) {
+    // WK == 1 (many row tiles: DenseCL rows): two waves per SIMD, so one workgroup's softmax / barrier / tile
+    // store overlaps the other's MFMA chain: 80.7 -> 108.8 TFLOP/s at 6272 x 65536 (9 spilled VGPRs).
     constexpr int NSUB = (WK == 1) ? 2 : 1;
     constexpr int KT = 32 * WK * NSUB, KP = KT + 1;
     extern __shared__ __attribute__((aligned(16))) float T[];
@@ -393,17 +420,31 @@ static int rowkey_shape(int R, int* WR, int* WK) {
 }
 
 CP2_API int cp2_rowkey_num_splits(int R, int K) {
-    // enough workgroups to fill 256 CUs about twice over, at least 2 LDS tiles of keys per split
+    // Workgroups = row blocks x key splits.  Two workgroups fit a CU (about 200 VGPRs, 33-67 KB LDS), so the chip
+    // holds 512 at once; a grid slightly above a multiple of 512 runs a nearly empty last wave (539 workgroups
+    // took as long as 1024 would).  Pick the split count whose last wave is fullest, preferring 2-3 waves so that
+    // uneven workgroups still balance, with at least 8 LDS tiles of keys per split (2 when there is one row block).
     if (R <= 0 || K <= 0) return CP2_ERR_SHAPE;
     int WR, WK;
     rowkey_shape(R, &WR, &WK);
     const int KT = 32 * WK * (WK == 1 ? 2 : 1);
     const int row_blocks = cp2_cdiv(R, 32 * WR);
-    int ns = cp2_cdiv(512, row_blocks);
-    const int max_ns = cp2_cdiv(K, 2 * KT);
-    if (ns > max_ns) ns = max_ns;
-    if (ns < 1) ns = 1;
-    return ns;
+    const int slots = 512;
+    const int max_ns = cp2_cdiv(K, (row_blocks == 1 ? 2 : 8) * KT) < 1 ? 1 : cp2_cdiv(K, (row_blocks == 1 ? 2 : 8) * KT);
+    int best = 1;
+    double best_score = -1.0;
+    for (int ns = 1; ns <= max_ns; ++ns) {
+        const int64_t blocks = (int64_t)row_blocks * ns;
+        const int64_t waves = (blocks + slots - 1) / slots;
+        if (waves > 3) break;
+        double eff = (double)blocks / (double)(waves * slots);
+        if (blocks < slots) eff = (double)blocks / slots;             // a partly filled chip
+        const double score = eff + 0.01 * (double)waves;  // ties: more waves balance better
+        if (score > best_score) { best_score = score; best = ns; }
+    }
+    // every split must own at least one key after rounding the split length up to whole tiles
+    while (best > 1 && (int64_t)(cp2_cdiv(cp2_cdiv(K, best), KT) * KT) * (best - 1) >= K) --best;
+    return best;
 }
 
 CP2_API int cp2_rowkey_infonce_fwd(const float* rows, int RP, int64_t r_sn, int64_t r_sx, int64_t r_sc, int R,
