@@ -224,6 +224,7 @@ class MODEL(nn.Module):
         self.cross_image_variance_target = AverageMeter("Cross_Image_Variance_Target", ":6.2f")
         self.correlation_ious, self.masked_correlation_ious = [], []
         self._flat_q = self._flat_k = None
+        self.log_quartiles = True        # per-step quartile statistics of the reference (builder.py:1298,1399-1406), sort-free
         self.ema_in_forward = True       # False: the caller runs _momentum_update_key_encoder() itself before forward
         self.overlap_key_branch = None   # key branch on a side stream: None = only when world size > 1 (no gain at N=1)
         self._side_stream = None
@@ -353,14 +354,27 @@ class MODEL(nn.Module):
 
         out = CF.cp2_loss_section(q, k, mask_a, mask_b, self.queue, temp_global=self.temp_global,
                                   temp_local=self.temp_local, lmbd_dense=self.lmbd_dense_loss,
-                                  include_background=self.include_background, ids=ids, weights=weights)
+                                  include_background=self.include_background, ids=ids, weights=weights,
+                                  want_quartiles=self.log_quartiles)
         self._dequeue_and_enqueue(out.k_pos)
-        self._log_step(step, b, {"train/loss_step": out.loss.detach(), "train/loss_ins_step": out.loss_instance,
-                                 "train/loss_dense_step": out.loss_dense, "train/acc_ins_step": out.acc1,
-                                 "train/acc_seg_step": out.acc_dense,
-                                 "train/+ive_scores_step": out.dense_sample[:, 3].mean(),
-                                 "train/-ive_scores_step": out.dense_sample[:, 4].mean(),
-                                 "step/instance_average_positive_scores": out.instance_pos.mean()})
+        logs = {"train/loss_step": out.loss.detach(), "train/loss_ins_step": out.loss_instance,
+                "train/loss_dense_step": out.loss_dense, "train/acc_ins_step": out.acc1,
+                "train/acc_seg_step": out.acc_dense,
+                "train/+ive_scores_step": out.dense_sample[:, 3].mean(),
+                "train/-ive_scores_step": out.dense_sample[:, 4].mean(),
+                "step/instance_average_positive_scores": out.instance_pos.mean()}
+        if self.log_quartiles:           # same scalar names as the reference's wandb.log (builder.py:1589-1601)
+            pq, nq, iq = out.dense_pos_quartiles.mean(1), out.dense_neg_quartiles.mean(1), out.instance_neg_quartiles.mean(1)
+            logs.update({"step/dense_per_sample_average_positive_scores": logs["train/+ive_scores_step"],
+                         "step/dense_per_sample_lower_positive_scores": pq[0], "step/dense_per_sample_median_positive_scores": pq[1],
+                         "step/dense_per_sample_upper_positive_scores": pq[2],
+                         "step/dense_per_sample_average_negative_scores": logs["train/-ive_scores_step"],
+                         "step/dense_per_sample_lower_negative_scores": nq[0], "step/dense_per_sample_median_negative_scores": nq[1],
+                         "step/dense_per_sample_upper_negative_scores": nq[2],
+                         "step/instance_average_negative_scores": out.instance_neg_mean.mean(),
+                         "step/instance_lower_negative_scores": iq[0], "step/instance_median_negative_scores": iq[1],
+                         "step/instance_upper_negative_scores": iq[2]})
+        self._log_step(step, b, logs)
         if new_epoch:
             self.epoch += 1
         return out.loss

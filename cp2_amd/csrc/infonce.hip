@@ -34,18 +34,18 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 // product 1 and the column read of product 2 are bank-conflict free).  The fill is split
 // in two so the global loads of the NEXT tile are in flight while the current one is used:
 // tile_load (global -> registers, 16 bytes per lane when aligned) ... tile_store (-> LDS).
-template <int KT>
+template <int KT, int NT = 256>
 struct TileRegs {
-    float4 v[CH * KT / 1024];
+    float4 v[CH * KT / 4 / NT];
 };
 
-template <int KT>
-__device__ __forceinline__ void tile_load(TileRegs<KT>& rg, const float* __restrict__ src, int64_t ld, int j0, int jmax,
+template <int KT, int NT = 256>
+__device__ __forceinline__ void tile_load(TileRegs<KT, NT>& rg, const float* __restrict__ src, int64_t ld, int j0, int jmax,
                                           int tid, bool vec_ok) {
     constexpr int Q = KT / 4;  // float4 per tile row
 #pragma unroll
-    for (int i = 0; i < CH * KT / 1024; ++i) {
-        const int e = tid + i * 256, c = e / Q, j = (e % Q) * 4;
+    for (int i = 0; i < CH * KT / 4 / NT; ++i) {
+        const int e = tid + i * NT, c = e / Q, j = (e % Q) * 4;
         const float* p = src + (int64_t)c * ld + j0 + j;
         if (vec_ok && j0 + j + 3 < jmax) {
             rg.v[i] = *reinterpret_cast<const float4*>(p);
@@ -58,24 +58,24 @@ __device__ __forceinline__ void tile_load(TileRegs<KT>& rg, const float* __restr
     }
 }
 
-template <int KT>
-__device__ __forceinline__ void tile_store(float* __restrict__ T, const TileRegs<KT>& rg, int tid) {
+template <int KT, int NT = 256>
+__device__ __forceinline__ void tile_store(float* __restrict__ T, const TileRegs<KT, NT>& rg, int tid) {
     constexpr int Q = KT / 4, KP = KT + 1;
 #pragma unroll
-    for (int i = 0; i < CH * KT / 1024; ++i) {
-        const int e = tid + i * 256, c = e / Q, j = (e % Q) * 4;
+    for (int i = 0; i < CH * KT / 4 / NT; ++i) {
+        const int e = tid + i * NT, c = e / Q, j = (e % Q) * 4;
         float* d = T + c * KP + j;
         d[0] = rg.v[i].x; d[1] = rg.v[i].y; d[2] = rg.v[i].z; d[3] = rg.v[i].w;
     }
 }
 
-template <int KT>
+template <int KT, int NT = 256>
 __device__ __forceinline__ void fill_tile(float* __restrict__ T, const float* __restrict__ src, int64_t ld, int j0,
                                           int jmax, int tid) {
-    TileRegs<KT> rg;
+    TileRegs<KT, NT> rg;
     const bool vec_ok = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) && (j0 % 4 == 0);
-    tile_load<KT>(rg, src, ld, j0, jmax, tid, vec_ok);
-    tile_store<KT>(T, rg, tid);
+    tile_load<KT, NT>(rg, src, ld, j0, jmax, tid, vec_ok);
+    tile_store<KT, NT>(T, rg, tid);
 }
 
 // S^T[other = kk + rho(reg,h)][owner = lane&31] for one 32x32 sub-tile.
@@ -521,6 +521,7 @@ struct DenseArgs {
     int P;
     // forward outputs, per key pixel y: [B][P]
     float* lse; float* colsum_a; float* possum; float* allsum; float* colmax; int* argx;
+    float* logits_out;                           // optional [B][P][P] raw logits (x-major), for the logging quantiles
     // backward
     const float* sample_scal;                    // [B][8]: Sa, Sb, ...
     float grad_scale; float* g_dense;            // [B][CH][P]
@@ -533,6 +534,19 @@ __device__ __forceinline__ float corr_weight(int64_t pa, int64_t pb, int64_t ra,
 }
 
 constexpr int DKT = 64, DKP = DKT + 1;
+#ifndef CP2_DNW
+#define CP2_DNW 4
+#endif
+constexpr int DNW = CP2_DNW, DNT = DNW * 64;  // dense workgroup = DNW waves = 32*DNW owner pixels
+
+// Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD group).  Every workgroup of a
+// sample streams that sample's whole other-side map (P x 128 floats), so the workgroups of one sample should
+// share one XCD's 4 MiB L2: linear id -> work item such that each XCD group owns a contiguous run of
+// (sample, tile) items (bijective for any grid size; MI355X guide T1).
+__device__ __forceinline__ int xcd_work_item(int id, int n_items) {
+    const int q = n_items / 8, rem = n_items % 8, xcd = id % 8, j = id / 8;
+    return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + j;
+}
 struct DenseLds {
     float T[CH * DKP];
     float ma[DKT]; float aux[DKT]; float aux2[DKT];
@@ -542,12 +556,14 @@ struct DenseLds {
 // owners = key pixels y (lane), others = query pixels x (LDS tile).  Column-wise softmax
 // statistics over x for every y, the masked column sums, and the logging sums.
 template <bool WEIGHTS>
-__global__ __launch_bounds__(256) void dense_fwd_kernel(DenseArgs a) {
+__global__ __launch_bounds__(DNT, 2) void dense_fwd_kernel(DenseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DenseLds& L = *reinterpret_cast<DenseLds*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int n = blockIdx.y, P = a.P;
-    const int y = (blockIdx.x * 4 + wid) * 32 + r;
+    const int P = a.P, tiles = (P + 32 * DNW - 1) / (32 * DNW);
+    const int item = xcd_work_item(blockIdx.x, gridDim.x);
+    const int n = item / tiles;
+    const int y = ((item % tiles) * DNW + wid) * 32 + r;
     const bool y_ok = y < P;
     const float* qd = a.qd + (int64_t)n * CH * P;
     const float* kd = a.kd + (int64_t)n * CH * P;
@@ -558,9 +574,13 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(DenseArgs a) {
     if (WEIGHTS && y_ok) { pb = a.pix_b[(int64_t)n * P + y]; rb = a.reg_b[(int64_t)n * P + y]; }
     float m_run = -INFINITY, s_run = 0.f, a_run = 0.f, pos_run = 0.f, all_run = 0.f, best_v = -INFINITY;
     int best_x = 0;
+    const bool vec_ok = (P % 4 == 0) && ((reinterpret_cast<uintptr_t>(qd) & 15u) == 0);
+    TileRegs<DKT, DNT> rg;
+    tile_load<DKT, DNT>(rg, qd, P, 0, P, tid, vec_ok);
     for (int x0 = 0; x0 < P; x0 += DKT) {
         __syncthreads();
-        fill_tile<DKT>(L.T, qd, P, x0, P, tid);
+        tile_store<DKT, DNT>(L.T, rg, tid);
+        if (x0 + DKT < P) tile_load<DKT, DNT>(rg, qd, P, x0 + DKT, P, tid, vec_ok);  // next tile in flight during the MFMAs
         if (tid < DKT) {
             const int x = x0 + tid;
             L.ma[tid] = x < P ? a.mask_a[(int64_t)n * P + x] : 0.f;
@@ -582,6 +602,7 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(DenseArgs a) {
                 const int xi = kk + rho(reg, h), x = x0 + xi;
                 const bool valid = x < P;
                 const float raw = acc[reg];
+                if (a.logits_out && valid && y_ok) a.logits_out[((int64_t)n * P + x) * P + y] = raw;
                 float w = 1.f;
                 if (WEIGHTS) w = corr_weight(L.pid[xi], pb, L.rid[xi], rb, a.w_pixel, a.w_region, a.w_not);
                 const float v = raw * w * a.inv_t;
@@ -692,12 +713,14 @@ __global__ __launch_bounds__(64) void dense_batch_kernel(const float* __restrict
 //   d loss_n / d Ls[x][y] = mb[y] (Sa softmax_x(Ls)[x][y] - ma[x]) / (Sa Sb),  Ls = L w / T
 //   g_dense[c][x] = grad_scale * sum_y kd[c][y] * (w/T) * dLs[x][y]
 template <bool WEIGHTS>
-__global__ __launch_bounds__(256) void dense_bwd_kernel(DenseArgs a) {
+__global__ __launch_bounds__(DNT, 2) void dense_bwd_kernel(DenseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DenseLds& L = *reinterpret_cast<DenseLds*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int n = blockIdx.y, P = a.P;
-    const int x = (blockIdx.x * 4 + wid) * 32 + r;
+    const int P = a.P, tiles = (P + 32 * DNW - 1) / (32 * DNW);
+    const int item = xcd_work_item(blockIdx.x, gridDim.x);
+    const int n = item / tiles;
+    const int x = ((item % tiles) * DNW + wid) * 32 + r;
     const bool x_ok = x < P;
     const float* qd = a.qd + (int64_t)n * CH * P;
     const float* kd = a.kd + (int64_t)n * CH * P;
@@ -712,9 +735,13 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseArgs a) {
     f32x16 U[4];
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) U[cb] = (f32x16){0};
+    const bool vec_ok = (P % 4 == 0) && ((reinterpret_cast<uintptr_t>(kd) & 15u) == 0);
+    TileRegs<DKT, DNT> rg;
+    tile_load<DKT, DNT>(rg, kd, P, 0, P, tid, vec_ok);
     for (int y0 = 0; y0 < P; y0 += DKT) {
         __syncthreads();
-        fill_tile<DKT>(L.T, kd, P, y0, P, tid);
+        tile_store<DKT, DNT>(L.T, rg, tid);
+        if (y0 + DKT < P) tile_load<DKT, DNT>(rg, kd, P, y0 + DKT, P, tid, vec_ok);  // next tile in flight during the MFMAs
         if (tid < DKT) {
             const int y = y0 + tid;
             L.ma[tid] = y < P ? a.mask_b[(int64_t)n * P + y] : 0.f;   // mb
@@ -768,16 +795,16 @@ CP2_API int cp2_dense_infonce_fwd(const float* q_dense, const float* k_dense, co
                                   const int64_t* reg_a, const int64_t* reg_b, float w_pixel, float w_region,
                                   float w_not, float temperature, float* lse, float* colsum_a, float* possum,
                                   float* allsum, float* colmax, int32_t* argx, float* sample_scal, float* batch_out,
-                                  int B, int C, int P, void* stream) {
+                                  float* logits_out, int B, int C, int P, void* stream) {
     int rc = dense_check(q_dense, k_dense, mask_a, mask_b, pix_a, pix_b, reg_a, reg_b, B, C, P, temperature);
     if (rc) return rc;
     if (!lse || !colsum_a || !possum || !allsum || !colmax || !argx || !sample_scal || !batch_out) return CP2_ERR_NULL;
     DenseArgs a{q_dense, k_dense, mask_a, mask_b, pix_a, pix_b, reg_a, reg_b, w_pixel, w_region, w_not,
-                1.0f / temperature, P, lse, colsum_a, possum, allsum, colmax, argx, nullptr, 0.f, nullptr};
-    const dim3 grid(cp2_cdiv(P, 128), B);
+                1.0f / temperature, P, lse, colsum_a, possum, allsum, colmax, argx, logits_out, nullptr, 0.f, nullptr};
+    const dim3 grid(cp2_cdiv(P, 32 * DNW) * B);
     const size_t lds = sizeof(DenseLds);
-    if (pix_a) hipLaunchKernelGGL(dense_fwd_kernel<true>, grid, dim3(256), lds, cp2_stream(stream), a);
-    else hipLaunchKernelGGL(dense_fwd_kernel<false>, grid, dim3(256), lds, cp2_stream(stream), a);
+    if (pix_a) hipLaunchKernelGGL(dense_fwd_kernel<true>, grid, dim3(DNT), lds, cp2_stream(stream), a);
+    else hipLaunchKernelGGL(dense_fwd_kernel<false>, grid, dim3(DNT), lds, cp2_stream(stream), a);
     rc = cp2_launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(dense_finalize_kernel, dim3(B), dim3(256), 0, cp2_stream(stream), a, sample_scal);
@@ -796,11 +823,11 @@ CP2_API int cp2_dense_infonce_bwd(const float* q_dense, const float* k_dense, co
     if (rc) return rc;
     if (!lse || !sample_scal || !g_dense) return CP2_ERR_NULL;
     DenseArgs a{q_dense, k_dense, mask_a, mask_b, pix_a, pix_b, reg_a, reg_b, w_pixel, w_region, w_not,
-                1.0f / temperature, P, const_cast<float*>(lse), nullptr, nullptr, nullptr, nullptr, nullptr,
+                1.0f / temperature, P, const_cast<float*>(lse), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                 sample_scal, grad_scale, g_dense};
-    const dim3 grid(cp2_cdiv(P, 128), B);
+    const dim3 grid(cp2_cdiv(P, 32 * DNW) * B);
     const size_t lds = sizeof(DenseLds);
-    if (pix_a) hipLaunchKernelGGL(dense_bwd_kernel<true>, grid, dim3(256), lds, cp2_stream(stream), a);
-    else hipLaunchKernelGGL(dense_bwd_kernel<false>, grid, dim3(256), lds, cp2_stream(stream), a);
+    if (pix_a) hipLaunchKernelGGL(dense_bwd_kernel<true>, grid, dim3(DNT), lds, cp2_stream(stream), a);
+    else hipLaunchKernelGGL(dense_bwd_kernel<false>, grid, dim3(DNT), lds, cp2_stream(stream), a);
     return cp2_launch_status();
 }

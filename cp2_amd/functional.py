@@ -28,13 +28,19 @@ class CP2LossOutputs:
     q_pos: torch.Tensor
     dense_sample: torch.Tensor       # [B,8] Sa, Sb, loss_n, mean +score, mean -score, arg-max label
     instance_pos: torch.Tensor       # [B] raw positive logit q_pos.k_pos
-    lnegT: Optional[torch.Tensor]    # [K,B] raw queue logits (only when want_lneg)
+    lnegT: Optional[torch.Tensor] = None                  # [K,B] raw queue logits (want_lneg / want_quartiles)
+    # logging quartiles (want_quartiles): [3,B] each = torch.(nan)quantile(..., [.25,.5,.75]) of the reference
+    dense_pos_quartiles: Optional[torch.Tensor] = None    # tools/correlation_mapping.py:16-53, positive pairs
+    dense_neg_quartiles: Optional[torch.Tensor] = None    # ... negative pairs
+    instance_neg_quartiles: Optional[torch.Tensor] = None # builder.py:1401-1406
+    instance_neg_mean: Optional[torch.Tensor] = None      # [B] builder.py:1400
 
 
 class _CP2LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q_feat, k_feat, mask_a, mask_b, queue, cfg):
-        (temp_global, temp_local, lmbd_dense, include_background, ids, weights, want_lneg) = cfg
+        (temp_global, temp_local, lmbd_dense, include_background, ids, weights, want_lneg, want_quart) = cfg
+        want_lneg = want_lneg or want_quart
         B = q_feat.shape[0]
         need_grad = q_feat.requires_grad
         q_dense, q_inv, q_part = ops.feat_normalize_pool(q_feat, mask_a)
@@ -46,7 +52,7 @@ class _CP2LossFn(torch.autograd.Function):
         C = q_pos.shape[1]
         ins = ops.rowkey_infonce(q_pos, (1, C, 0, 1), B, queue, ext, temp_global,
                                  grad_scale=(1.0 / B) if need_grad else None, want_lneg=want_lneg)
-        den = ops.dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temp_local, ids, weights)
+        den = ops.dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temp_local, ids, weights, want_logits=want_quart)
         loss = ins.loss + den.loss * lmbd_dense
         if need_grad:
             g_dense = ops.dense_infonce_bwd(q_dense, k_dense, mask_a, mask_b, temp_local, den, lmbd_dense / B, ids, weights)
@@ -63,6 +69,11 @@ class _CP2LossFn(torch.autograd.Function):
         outs = (loss, ins.loss, den.loss, den.acc, acc1, acc5, k_pos, q_pos, den.sample_scal, extras[:, 0].contiguous())
         if want_lneg:
             outs = outs + (ins.lnegT,)
+        if want_quart:
+            K = queue.shape[1]
+            outs = outs + (ops.masked_quantiles(den.logits, P * P, 1, B, P * P, mask_a=mask_a, mask_b=mask_b, want=1),
+                           ops.masked_quantiles(den.logits, P * P, 1, B, P * P, mask_a=mask_a, mask_b=mask_b, want=0),
+                           ops.masked_quantiles(ins.lnegT, 1, B, B, K), ins.lnegT.mean(0))
         ctx.mark_non_differentiable(*outs[1:])
         return outs
 
@@ -75,7 +86,8 @@ class _CP2LossFn(torch.autograd.Function):
 def cp2_loss_section(q_feat: torch.Tensor, k_feat: torch.Tensor, mask_a: torch.Tensor, mask_b: torch.Tensor,
                      queue: torch.Tensor, *, temp_global: float = 0.2, temp_local: float = 1.0,
                      lmbd_dense: float = 0.2, include_background: bool = False, ids=None,
-                     weights: Tuple[float, float, float] = (1.0, 1.0, 1.0), want_lneg: bool = False) -> CP2LossOutputs:
+                     weights: Tuple[float, float, float] = (1.0, 1.0, 1.0), want_lneg: bool = False,
+                     want_quartiles: bool = False) -> CP2LossOutputs:
     """q_feat / k_feat: encoder outputs [B,128,h,w] (NCHW or channels-last, fp32; k already
     un-shuffled, no grad); mask_a / mask_b: [B,P] down-sampled foreground masks; queue [128,K].
     ids = (pixel_ids_a, pixel_ids_b, region_ids_a, region_ids_b) int64 [B,P] when the
@@ -83,6 +95,13 @@ def cp2_loss_section(q_feat: torch.Tensor, k_feat: torch.Tensor, mask_a: torch.T
     if ids is not None and tuple(float(w) for w in weights) == (1.0, 1.0, 1.0):
         ids = None                                   # all weights one: the predicate is never needed
     cfg = (float(temp_global), float(temp_local), float(lmbd_dense), bool(include_background), ids,
-           tuple(float(w) for w in weights), bool(want_lneg))
+           tuple(float(w) for w in weights), bool(want_lneg), bool(want_quartiles))
     outs = _CP2LossFn.apply(q_feat, k_feat.detach(), mask_a, mask_b, queue, cfg)
-    return CP2LossOutputs(*outs[:10], lnegT=outs[10] if want_lneg else None)
+    res = CP2LossOutputs(*outs[:10])
+    i = 10
+    if want_lneg or want_quartiles:
+        res.lnegT = outs[i]
+        i += 1
+    if want_quartiles:
+        res.dense_pos_quartiles, res.dense_neg_quartiles, res.instance_neg_quartiles, res.instance_neg_mean = outs[i:i + 4]
+    return res

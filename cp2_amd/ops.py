@@ -305,7 +305,7 @@ def rowkey_infonce(rows: torch.Tensor, row_layout: Tuple[int, int, int, int], R:
 
 # ---------------------------------------------------------------- a8 / a9
 class DenseResult:
-    __slots__ = ("loss", "acc", "lse", "sample_scal", "colmax", "argx")
+    __slots__ = ("loss", "acc", "lse", "sample_scal", "colmax", "argx", "logits")
 
 
 def _ids4(ids):
@@ -317,7 +317,7 @@ def _ids4(ids):
 
 
 def dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temperature: float, ids=None,
-                      weights=(1.0, 1.0, 1.0)) -> DenseResult:
+                      weights=(1.0, 1.0, 1.0), want_logits: bool = False) -> DenseResult:
     lib = _lib.load()
     B, C, P = q_dense.shape
     dev = q_dense.device
@@ -327,13 +327,14 @@ def dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temperature: float, ids=
     res.argx = torch.empty((B, P), dtype=torch.int32, device=dev)
     res.sample_scal = torch.empty((B, 8), dtype=torch.float32, device=dev)
     batch = torch.empty(2, dtype=torch.float32, device=dev)
+    res.logits = torch.empty((B, P, P), dtype=torch.float32, device=dev) if want_logits else None
     pa, pb, ra, rb = _ids4(ids)
     rc = lib.cp2_dense_infonce_fwd(_dev(q_dense, "q_dense", torch.float32), _dev(k_dense, "k_dense", torch.float32),
                                    _dev(mask_a, "mask_a", torch.float32), _dev(mask_b, "mask_b", torch.float32),
                                    pa, pb, ra, rb, float(weights[0]), float(weights[1]), float(weights[2]),
                                    float(temperature), res.lse.data_ptr(), colsum.data_ptr(), possum.data_ptr(),
                                    allsum.data_ptr(), res.colmax.data_ptr(), res.argx.data_ptr(),
-                                   res.sample_scal.data_ptr(), batch.data_ptr(), B, C, P, _stream())
+                                   res.sample_scal.data_ptr(), batch.data_ptr(), _opt(res.logits, "logits"), B, C, P, _stream())
     _lib.check(rc, "cp2_dense_infonce_fwd")
     res.loss, res.acc = batch[0], batch[1]
     return res
@@ -351,3 +352,33 @@ def dense_infonce_bwd(q_dense, k_dense, mask_a, mask_b, temperature: float, fwd:
                                    float(grad_scale), g.data_ptr(), B, C, P, _stream())
     _lib.check(rc, "cp2_dense_infonce_bwd")
     return g
+
+
+# ---------------------------------------------------------------- a15
+_QUARTILES = {}
+
+
+def _quartile_tensor(device) -> torch.Tensor:
+    key = str(device)
+    if key not in _QUARTILES:
+        _QUARTILES[key] = torch.tensor([0.25, 0.5, 0.75], dtype=torch.float32, device=device)
+    return _QUARTILES[key]
+
+
+def masked_quantiles(x: torch.Tensor, stride_row: int, stride_elem: int, R: int, N: int, q: Optional[torch.Tensor] = None,
+                     mask_a: Optional[torch.Tensor] = None, mask_b: Optional[torch.Tensor] = None, want: int = -1) -> torch.Tensor:
+    """out[j, r] = nanquantile of the kept elements of row r at q[j] (linear interpolation), no sort.
+    want = -1 keeps everything; 1 / 0 keep the positive / negative pairs of a [P,P] logit map per row
+    (reference tools/correlation_mapping.py:16-53, builder.py:1399-1406)."""
+    lib = _lib.load()
+    if q is None:
+        q = _quartile_tensor(x.device)
+    out = torch.empty((q.numel(), R), dtype=torch.float32, device=x.device)
+    P = mask_a.shape[1] if mask_a is not None else 0
+    if not x.is_cuda or x.dtype != torch.float32:
+        raise _lib.Cp2LibraryError("masked_quantiles: x must be a float32 GPU tensor")
+    rc = lib.cp2_masked_quantiles(x.data_ptr(), stride_row, stride_elem, R, N, _opt(mask_a, "mask_a", torch.float32),
+                                  _opt(mask_b, "mask_b", torch.float32), P, want, _dev(q, "q", torch.float32), q.numel(),
+                                  out.data_ptr(), _stream())
+    _lib.check(rc, "cp2_masked_quantiles")
+    return out

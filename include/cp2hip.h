@@ -140,18 +140,28 @@ int cp2_rowkey_infonce_finalize(const float* part_m, const float* part_s, const 
  * (pixel match -> w_pixel, else known-region match -> w_region, else w_not); NULL = all weights 1.
  * Per key pixel outputs [B,P]: lse, colsum_a, possum, allsum, colmax, argx (workspaces kept for backward /
  * logging).  sample_scal [B,8] = {Sa, Sb, loss_n, mean positive score, mean negative score, label at the
- * arg-max pair, 0, 0};  batch_out[2] = {mean_n loss_n, 100 * mean_n label}.   C = 128. */
+ * arg-max pair, 0, 0};  batch_out[2] = {mean_n loss_n, 100 * mean_n label}.
+ * logits_out: NULL, or [B,P,P] to also receive the raw logits q.k (only for the logging quantiles).   C = 128. */
 int cp2_dense_infonce_fwd(const float* q_dense, const float* k_dense, const float* mask_a, const float* mask_b,
                           const int64_t* pix_a, const int64_t* pix_b, const int64_t* reg_a, const int64_t* reg_b,
                           float w_pixel, float w_region, float w_not, float temperature, float* lse,
                           float* colsum_a, float* possum, float* allsum, float* colmax, int32_t* argx,
-                          float* sample_scal, float* batch_out, int B, int C, int P, void* stream);
+                          float* sample_scal, float* batch_out, float* logits_out, int B, int C, int P, void* stream);
 /* g_dense [B,C,P] = grad_scale * d (sum_n loss_n) / d q_dense, recomputing the logits tile by tile. */
 int cp2_dense_infonce_bwd(const float* q_dense, const float* k_dense, const float* mask_a, const float* mask_b,
                           const int64_t* pix_a, const int64_t* pix_b, const int64_t* reg_a, const int64_t* reg_b,
                           float w_pixel, float w_region, float w_not, float temperature, const float* lse,
                           const float* sample_scal, float grad_scale, float* g_dense, int B, int C, int P,
                           void* stream);
+
+/* ---- a15: logging quantiles without a sort ---------------- tools/correlation_mapping.py:16-53, builder.py:1399-1406
+ * out[j, r] = torch.nanquantile(kept elements of row r, q[j]) with linear interpolation (exact order statistics by
+ * radix select).  Element i of row r is x[r*stride_row + i*stride_elem], i < N.  want < 0: every element is kept;
+ * want = 1 / 0: N = P*P and element i = x_pix*P + y_pix is kept iff (mask_a[r,x_pix]*mask_b[r,y_pix] != 0) == want
+ * (the reference's positive / negative dense scores).  q: device float[NQ]; out: [NQ,R].  NaN when nothing is kept. */
+int cp2_masked_quantiles(const float* x, int64_t stride_row, int64_t stride_elem, int R, int N,
+                         const float* mask_a, const float* mask_b, int P, int want, const float* q, int NQ,
+                         float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -55,7 +55,7 @@ def test_loss_section_golden(golden_dir, name):
         ids = tuple(G(g[k]).reshape(b, -1) for k in ("pixel_ids_a", "pixel_ids_b", "region_ids_a", "region_ids_b"))
     out = CF.cp2_loss_section(q, G(g["k_feat"]), G(g["mask_a"]), G(g["mask_b"]), G(g["queue_before"]),
                               temp_global=tg, temp_local=tl, lmbd_dense=lmbd, include_background=bool(inc_bg),
-                              ids=ids, weights=(wp, wr, wn), want_lneg=True)
+                              ids=ids, weights=(wp, wr, wn), want_lneg=True, want_quartiles=True)
     out.loss.backward()
     assert_close(out.q_pos, g["q_pos"], 2e-6, what="q_pos")
     assert_close(out.k_pos, g["k_pos"], 2e-6, what="k_pos")
@@ -70,6 +70,11 @@ def test_loss_section_golden(golden_dir, name):
     assert_close(out.acc5, g["acc5"], 1e-4, what="acc5")
     assert_close(out.dense_sample[:, 3], g["dense_positive_average"], 2e-6, what="dense +mean")
     assert_close(out.dense_sample[:, 4], g["dense_negative_average"], 2e-6, what="dense -mean")
+    # a15 quartiles (reference: torch.nanquantile / torch.quantile on sorted data)
+    assert_close(out.dense_pos_quartiles, g["dense_positive_quartiles"], 3e-6, what="dense + quartiles")
+    assert_close(out.dense_neg_quartiles, g["dense_negative_quartiles"], 3e-6, what="dense - quartiles")
+    assert_close(out.instance_neg_quartiles, g["instance_negative_quartiles"], 3e-6, what="instance quartiles")
+    assert_close(out.instance_neg_mean, g["instance_average_negative_scores"], 3e-6, what="instance - mean")
 
 
 def test_feat_kernels_vs_oracle_and_channels_last():
@@ -200,3 +205,36 @@ def test_rowkey_large_split_property():
     got_rows = got.drows.permute(0, 2, 1).reshape(-1, C)[:rs]
     grad_close(got_rows, r_cpu.grad, "slice d rows")
     grad_close(got.dE[:, 0], p_cpu.grad, "slice d pos")
+
+
+def test_masked_quantiles_bit_exact_vs_torch():
+    """Same input -> the radix-select quantiles equal torch.quantile / torch.nanquantile bit for bit
+    (the reference's convention, tests/test_contrastive_metrics.py:50-57)."""
+    kat = torch.tensor([[1., 2, 3, 4, 5, 6], [1, 2, 3, 7, 8, 9]])
+    got = ops.masked_quantiles(kat.to(DEV), 6, 1, 2, 6)
+    assert torch.equal(got.cpu(), torch.tensor([[2.25, 2.25], [3.5, 5.0], [4.75, 7.75]]))
+    gen = torch.Generator().manual_seed(0)
+    for R, N in ((32, 65536), (5, 1000), (3, 7), (4, 1)):
+        x = torch.randn(R, N, generator=gen)
+        x[0, : N // 2] = 0.5                                    # heavy duplicates
+        if N > 4:
+            x[1, ::3] = float("nan")
+            x[1, 1] = -0.0
+        qs = torch.tensor([0.0, 0.1, 0.25, 0.5, 0.75, 0.999, 1.0])
+        want = torch.nanquantile(x, qs, dim=1)
+        got = ops.masked_quantiles(x.to(DEV), N, 1, R, N, q=qs.to(DEV))
+        assert torch.equal(got.cpu(), want), (R, N)
+        xt = x.t().contiguous()                                 # key-major storage, as lnegT
+        got_t = ops.masked_quantiles(xt.to(DEV), 1, R, R, N, q=qs.to(DEV))
+        assert torch.equal(got_t.cpu(), want), (R, N, "strided")
+    # masked form against the oracle's dense statistics
+    B, P = 3, 37
+    logits = torch.randn(B, P, P, generator=gen)
+    ma = (torch.rand(B, P, generator=gen) > 0.4).float()
+    mb = (torch.rand(B, P, generator=gen) > 0.5).float()
+    mb[2] = 0.0                                                 # no positives in sample 2 -> NaN, negatives = everything
+    st = O.dense_loss_stats(logits, ma[:, :, None] * mb[:, None, :])
+    pos = ops.masked_quantiles(logits.to(DEV), P * P, 1, B, P * P, mask_a=ma.to(DEV), mask_b=mb.to(DEV), want=1)
+    neg = ops.masked_quantiles(logits.to(DEV), P * P, 1, B, P * P, mask_a=ma.to(DEV), mask_b=mb.to(DEV), want=0)
+    assert np.array_equal(pos.cpu().numpy(), st["positive"]["quartiles"].numpy(), equal_nan=True)
+    assert np.array_equal(neg.cpu().numpy(), st["negative"]["quartiles"].numpy(), equal_nan=True)
