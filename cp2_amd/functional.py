@@ -73,7 +73,8 @@ class _CP2LossFn(torch.autograd.Function):
             K = queue.shape[1]
             outs = outs + (ops.masked_quantiles(den.logits, P * P, 1, B, P * P, mask_a=mask_a, mask_b=mask_b, want=1),
                            ops.masked_quantiles(den.logits, P * P, 1, B, P * P, mask_a=mask_a, mask_b=mask_b, want=0),
-                           ops.masked_quantiles(ins.lnegT, 1, B, B, K), ins.lnegT.mean(0))
+                           # the kernel wants contiguous rows: one 8 MB transpose beats 18 strided passes (356 -> ~40 us)
+                           ops.masked_quantiles(ins.lnegT.t().contiguous(), K, 1, B, K), ins.lnegT.mean(0))
         ctx.mark_non_differentiable(*outs[1:])
         return outs
 
