@@ -46,6 +46,7 @@ def parse():
                         "gradients of four 1x1 convolutions come back as garbage under graph REPLAY (DESIGN.md section 5); "
                         "eager mode is within 2 %% of the graph anyway (the GPU is saturated)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--fused-bn", default="on", choices=["on", "off"], help="encoder fast path: fused BN(+add)(+ReLU) kernels (A/B)")
     p.add_argument("--overlap", default="auto", choices=["auto", "on", "off"],
                    help="key branch (EMA, shuffle all-gathers, key encoder) on a side HIP stream; auto = when N > 1")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
@@ -86,6 +87,8 @@ def main():
         dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from cp2_amd import builder, ops, synthetic
+    from cp2_amd.encoder import FusedBatchNorm2d
+    FusedBatchNorm2d.fused = args.fused_bn == "on"
     from cp2_amd.config import Config
     from cp2_amd.engine import TrainStep
     from cp2_amd.main import make_optimizer

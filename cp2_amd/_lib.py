@@ -36,6 +36,9 @@ SIGNATURES = {
                                     c_int64, c_int64, _P, _P, _P, _P, _P, _P, c_int, _P],
     "cp2_dense_infonce_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, _P, _P, _P, _P,
                               _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
+    "cp2_bn_num_partials": [c_int, c_int],
+    "cp2_bn_fwd": [_P, _P, _P, _P, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P],
+    "cp2_bn_bwd": [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, _P],
     "cp2_masked_quantiles": [_P, c_int64, c_int64, c_int, c_int, _P, _P, c_int, c_int, _P, c_int, _P, _P],
     "cp2_dense_infonce_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, _P, _P, c_float,
                               _P, c_int, c_int, c_int, _P],

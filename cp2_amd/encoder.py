@@ -26,6 +26,60 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+from . import ops as _bn_ops  # noqa: E402  (ctypes front end; only touched on the GPU fast path)
+
+
+class _FusedBNFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, momentum, eps, relu):
+        ops = _bn_ops
+        y, stats = ops.bn_fwd(x, residual, weight, bias, running_mean, running_var, momentum, eps, relu)
+        ctx.save_for_backward(x, y if relu else None, weight, stats)
+        ctx.relu, ctx.has_res = relu, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ops = _bn_ops
+        x, y, weight, stats = ctx.saved_tensors
+        if dy.dtype != torch.bfloat16 or not dy.is_contiguous(memory_format=torch.channels_last):
+            dy = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        dx, dres, dgamma, dbeta = ops.bn_bwd(x, dy, y, weight, stats, ctx.relu, ctx.has_res)
+        return dx, dgamma, dbeta, dres, None, None, None, None, None
+
+
+class FusedBatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d (same parameters, buffers and state-dict keys) whose training forward on channels-last bf16
+    GPU activations is the fused BN (+ residual) (+ ReLU) kernel set of cp2_amd/csrc/bn.hip; anything else
+    (fp32, eval mode, NCHW, CPU) takes the stock PyTorch path.  `num_batches_tracked` is advanced lazily (it only
+    matters when momentum is None, which is never fused)."""
+
+    fused = True            # class-wide switch (bench.py --fused-bn off for A/B)
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self._pending_batches = 0
+
+    def forward(self, x, residual=None, relu=False):
+        if (FusedBatchNorm2d.fused and self.training and x.dtype == torch.bfloat16 and x.is_cuda
+                and self.track_running_stats and self.momentum is not None and self.affine
+                and self.weight.dtype == torch.float32 and _bn_ops.bn_supported(x)
+                and (residual is None or (residual.shape == x.shape and _bn_ops.bn_supported(residual)))):
+            self._pending_batches += 1
+            return _FusedBNFn.apply(x, self.weight, self.bias, residual, self.running_mean, self.running_var,
+                                    self.momentum, self.eps, relu)
+        y = super().forward(x)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu else y
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        if self._pending_batches and self.num_batches_tracked is not None:
+            self.num_batches_tracked += self._pending_batches
+            self._pending_batches = 0
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+
 class ConvBNAct(nn.Module):
     """conv -> BN -> ReLU with mmcv ConvModule's sub-module names (`conv`, `bn`, `activate`)."""
 
@@ -33,19 +87,19 @@ class ConvBNAct(nn.Module):
         super().__init__()
         self.conv = nn.Conv2d(cin, cout, k, padding=padding, dilation=dilation, bias=not norm)
         if norm:
-            self.bn = nn.BatchNorm2d(cout)
+            self.bn = FusedBatchNorm2d(cout)
         self.activate = nn.ReLU(inplace=True)
         self.with_norm = norm
 
     def forward(self, x):
         x = self.conv(x)
         if self.with_norm:
-            x = self.bn(x)
+            return self.bn(x, relu=True)
         return self.activate(x)
 
 
 def _downsample(cin, cout, stride):
-    return nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride, bias=False), nn.BatchNorm2d(cout))
+    return nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride, bias=False), FusedBatchNorm2d(cout))
 
 
 class BasicBlock(nn.Module):
@@ -54,17 +108,16 @@ class BasicBlock(nn.Module):
     def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None):
         super().__init__()
         self.conv1 = nn.Conv2d(inplanes, planes, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
+        self.bn1 = FusedBatchNorm2d(planes)
         self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
+        self.bn2 = FusedBatchNorm2d(planes)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
 
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)
-        y = self.relu(self.bn1(self.conv1(x)))
-        y = self.bn2(self.conv2(y))
-        return self.relu(y + idt)
+        y = self.bn1(self.conv1(x), relu=True)
+        return self.bn2(self.conv2(y), residual=idt, relu=True)
 
 
 class Bottleneck(nn.Module):
@@ -73,20 +126,19 @@ class Bottleneck(nn.Module):
     def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None):
         super().__init__()   # style='pytorch': the stride sits on the 3x3 conv
         self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
+        self.bn1 = FusedBatchNorm2d(planes)
         self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
+        self.bn2 = FusedBatchNorm2d(planes)
         self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
-        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.bn3 = FusedBatchNorm2d(planes * 4)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
 
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)
-        y = self.relu(self.bn1(self.conv1(x)))
-        y = self.relu(self.bn2(self.conv2(y)))
-        y = self.bn3(self.conv3(y))
-        return self.relu(y + idt)
+        y = self.bn1(self.conv1(x), relu=True)
+        y = self.bn2(self.conv2(y), relu=True)
+        return self.bn3(self.conv3(y), residual=idt, relu=True)
 
 
 _ARCH = {18: (BasicBlock, (2, 2, 2, 2)), 34: (BasicBlock, (3, 4, 6, 3)), 50: (Bottleneck, (3, 4, 6, 3)),
@@ -107,7 +159,7 @@ class ResNet(nn.Module):
         self.depth, self.out_indices, self.norm_eval = depth, tuple(out_indices), norm_eval
         self.zero_init_residual, self.init_cfg = zero_init_residual, init_cfg
         self.conv1 = nn.Conv2d(in_channels, stem_channels, 7, stride=2, padding=3, bias=False)
-        self.bn1 = nn.BatchNorm2d(stem_channels)
+        self.bn1 = FusedBatchNorm2d(stem_channels)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
         inplanes = stem_channels
@@ -153,7 +205,7 @@ class ResNet(nn.Module):
                     nn.init.zeros_(m.bn2.weight)
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(self.bn1(self.conv1(x), relu=True))
         outs = []
         for i, name in enumerate(self.res_layers):
             x = getattr(self, name)(x)

@@ -32,3 +32,11 @@ def test_ema_scalars_follow_python_double_arithmetic():
     m32, om32 = ops.ema_scalars(0.999)
     assert m32 == float(np.float32(0.999))
     assert om32 == float(np.float32(1.0 - 0.999)) and om32 != float(np.float32(1.0) - np.float32(0.999))
+
+
+def test_bn_partial_count_matches_library():
+    lib = _lib.load()
+    for M in (1, 3, 6272, 25088, 100352, 401408, 777):
+        for C in (64, 128, 256, 512, 1024, 2048):
+            assert ops._bn_partials(M, C) == lib.cp2_bn_num_partials(M, C), (M, C)
+    assert lib.cp2_bn_num_partials(100, 96) == -3 and lib.cp2_bn_num_partials(100, 4096) == -3
