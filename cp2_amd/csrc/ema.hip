@@ -14,7 +14,7 @@ __device__ __forceinline__ float4 ema4(float4 k, float4 q, float m, float om) {
                        ema1(k.w, q.w, m, om));
 }
 
-// Flat span, tuned on MI355X (scratch/ema_tune*.hip, kernel-exact events, infinity cache flushed
+// Flat span, tuned on MI355X (tools/ema_tune.hip, kernel-exact events, infinity cache flushed
 // between launches): 128-thread workgroups, ONE 16-byte element per lane, exact grid, and
 // non-temporal loads/stores (every byte is touched once per step, so nothing should linger in
 // L2 / MALL) reached 6.4-6.5 TB/s = 81 % of the 8 TB/s HBM3E peak; 256 threads x 4 elements
