@@ -1,0 +1,43 @@
+"""GPU: `python -m cp2_amd.main` end to end on BASELINE config 1 shapes (ResNet-18, 64x64 crops, queue 1024):
+runs two short epochs with the synthetic loader and checks the checkpoint contract the reference's fine-tuning
+loader relies on (main.py:528-550,661-670; networks/segment_network.py:79-92)."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(600)
+def test_main_cli_synthetic_and_checkpoint(tmp_path):
+    cmd = [sys.executable, "-m", "cp2_amd.main", "--config", os.path.join(ROOT, "configs", "config_pretrain_r18.py"),
+           "--run_id", "t", "--log_dir", str(tmp_path), "--synthetic", "--pretrain_from_scratch", "--queue_size", "1024",
+           "--img_height", "64", "--img_width", "64", "-b", "8", "--epochs", "2", "--steps_per_epoch", "3", "--lr", "0.01",
+           "--dist-url", "tcp://127.0.0.1:29533", "--print-freq", "1", "--include_background"]
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=550)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert "Epoch: [1][2/3]" in res.stdout
+    ck_path = tmp_path / "t" / "checkpoint.ckpt"
+    assert ck_path.exists() and (tmp_path / "t" / "6_1_checkpoint.ckpt").exists()
+    ck = torch.load(ck_path, map_location="cpu", weights_only=False)
+    assert ck["epoch"] == 2 and ck["pretrain_type"] == "CP2" and ck["backbone_type"] == "DEEPLABV3"
+    sd = ck["state_dict"]
+    for k in ("module.queue", "module.queue_ptr", "module.queue2", "module.encoder_q.backbone.conv1.weight",
+              "module.encoder_q.backbone.bn1.num_batches_tracked", "module.encoder_k.decode_head.contrast_conv.2.weight"):
+        assert k in sd, k
+    assert sd["module.queue"].shape == (128, 1024) and int(sd["module.queue_ptr"]) == (6 * 8) % 1024
+    assert int(sd["module.encoder_q.backbone.bn1.num_batches_tracked"]) >= 6          # lazily counted fused-BN steps
+    # what reference segment_network.py:84-92 does with it: keep encoder_q.*, strip the prefix, drop conv_seg
+    enc = {k.replace("module.encoder_q.", ""): v for k, v in sd.items() if "encoder_q." in k and "conv_seg" not in k}
+    from cp2_amd.config import Config
+    from cp2_amd.encoder import build_segmentor
+    m = build_segmentor(Config.fromfile(os.path.join(ROOT, "configs", "config_pretrain_r18.py")).model)
+    missing, unexpected = m.load_state_dict(enc, strict=False)
+    assert not unexpected and all("conv_seg" in k for k in missing)
+    assert all(torch.isfinite(v).all() for v in enc.values() if v.dtype.is_floating_point)
+    assert len(ck["optimizer"]["state"]) > 20
