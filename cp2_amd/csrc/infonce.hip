@@ -273,6 +273,180 @@ __global__ __launch_bounds__(256, WK == 1 ? 2 : 1) void rowkey_fwd_kernel(RowKey
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Split-bf16 variant of rowkey_fwd_kernel<4,1,*> for the MFMA-bound case (thousands of rows, config 5).
+// Every fp32 operand x is used as hi + lo with hi = bf16(x), lo = bf16(x - hi) and every product as
+// hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulate): 3 MFMAs of 32 cycles replace 8 f32 MFMAs of
+// 64 cycles per 32x32x16 block (5.3x fewer matrix-pipe cycles) at <= 3*2^-18 relative error per term, i.e. <= 1.2e-5
+// on logits of unit vectors (the reference bound is 1e-4).  Same orientation, partial-state layout and finalize as
+// the f32 kernel; only the LDS images and the two products differ:
+//   image 1 (product 1: keys x channels)  T1[key][c]  bf16, 272-byte rows -> conflict-free 16-byte A-fragment reads
+//   image 2 (product 2: channels x keys)  T2[c][key]  bf16, 136-byte rows -> conflict-free 8-byte reads; the 8 keys
+//           of a fragment follow the accumulator's row order 16s + 8(j>>2) + 4h + (j&3), so the soft-max
+//           accumulator registers 8s..8s+7 are the B fragment of k-step s with no lane movement.
+// Both images are produced in-kernel from the fp32 [C][K] queue (no extra global state to maintain).
+// ---------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x16 mfma_bf(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+constexpr int BKT = 64;                      // keys per LDS tile
+constexpr int T1P = 272, T2P = 136;          // row pitches in bytes
+constexpr int T1B = BKT * T1P, T2B = CH * T2P;
+constexpr int BF_LDS = 2 * T1B + 2 * T2B;    // T1 hi | T1 lo | T2 hi | T2 lo = 69632 bytes
+
+__device__ __forceinline__ void split_bf(float v, __bf16& hi, __bf16& lo) {
+    hi = (__bf16)v;
+    lo = (__bf16)(v - (float)hi);
+}
+
+__device__ __forceinline__ void tile_store_bf(unsigned char* __restrict__ sm, const TileRegs<BKT>& rg, int tid) {
+#pragma unroll
+    for (int i = 0; i < CH * BKT / 1024; ++i) {
+        const int e = tid + i * 256, c = e / (BKT / 4), j = (e % (BKT / 4)) * 4;
+        const float v[4] = {rg.v[i].x, rg.v[i].y, rg.v[i].z, rg.v[i].w};
+        bf16x4 h4, l4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            __bf16 hi, lo;
+            split_bf(v[u], hi, lo);
+            h4[u] = hi; l4[u] = lo;
+            *reinterpret_cast<__bf16*>(sm + (j + u) * T1P + c * 2) = hi;
+            *reinterpret_cast<__bf16*>(sm + T1B + (j + u) * T1P + c * 2) = lo;
+        }
+        *reinterpret_cast<bf16x4*>(sm + 2 * T1B + c * T2P + j * 2) = h4;
+        *reinterpret_cast<bf16x4*>(sm + 2 * T1B + T2B + c * T2P + j * 2) = l4;
+    }
+}
+
+template <bool WITH_U>
+__global__ __launch_bounds__(256, 2) void rowkey_fwd_bf16x3_kernel(RowKeyArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int row = (blockIdx.x * 4 + wid) * 32 + r;
+    const bool row_ok = row < a.R;
+    bf16x8 bqh[CH / 16], bql[CH / 16];
+    {
+        const int rr = row_ok ? row : 0;
+        const float* base = a.rows + (int64_t)(rr / a.RP) * a.r_sn + (int64_t)(rr % a.RP) * a.r_sx;
+#pragma unroll
+        for (int st = 0; st < CH / 16; ++st) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = row_ok ? base[(int64_t)(16 * st + 8 * h + j) * a.r_sc] : 0.f;
+                __bf16 hi, lo;
+                split_bf(v, hi, lo);
+                bqh[st][j] = hi; bql[st][j] = lo;
+            }
+        }
+    }
+    const float pos_s = (row_ok && a.NE > 0) ? a.extras[(int64_t)row * a.NE] * a.inv_t : INFINITY;
+    float m_run = -INFINITY, s_run = 0.f;
+    int cnt = 0;
+    f32x16 U[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) U[cb] = (f32x16){0};
+    const int k_begin = blockIdx.y * a.keys_per_split;
+    const int k_end = min(a.K, k_begin + a.keys_per_split);
+    const bool vec_ok = (a.K % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.keys) & 15u) == 0);
+    TileRegs<BKT> rg;
+    tile_load<BKT>(rg, a.keys, a.K, k_begin, k_end, tid, vec_ok);
+    for (int k0 = k_begin; k0 < k_end; k0 += BKT) {
+        __syncthreads();
+        tile_store_bf(smb, rg, tid);
+        __syncthreads();
+        if (k0 + BKT < k_end) tile_load<BKT>(rg, a.keys, a.K, k0 + BKT, k_end, tid, vec_ok);
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int kk = sub * 32;
+            if (k0 + kk >= k_end) continue;  // wave-uniform
+            f32x16 acc = {0};
+            {
+                const unsigned char* p1 = smb + (kk + r) * T1P + h * 16;
+#pragma unroll
+                for (int st = 0; st < CH / 16; ++st) {
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(p1 + st * 32);
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(p1 + T1B + st * 32);
+                    acc = mfma_bf(ah, bqh[st], acc);
+                    acc = mfma_bf(ah, bql[st], acc);
+                    acc = mfma_bf(al, bqh[st], acc);
+                }
+            }
+            float sv[16];
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int key = k0 + kk + rho(reg, h);
+                const bool valid = key < k_end;
+                if (a.lnegT && valid && row_ok) a.lnegT[(int64_t)key * a.R + row] = acc[reg];
+                sv[reg] = valid ? acc[reg] * a.inv_t : -INFINITY;
+                tmax = fmaxf(tmax, sv[reg]);
+                cnt += (sv[reg] > pos_s) ? 1 : 0;
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            if (__any(tmax > m_run)) {
+                const float m_new = fmaxf(m_run, tmax);
+                const float sc = __expf(m_run - m_new);
+                s_run *= sc;
+                if (WITH_U) {
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) U[cb] *= sc;
+                }
+                m_run = m_new;
+            }
+            float p[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                p[reg] = __expf(sv[reg] - m_run);
+                s_run += p[reg];
+            }
+            if (WITH_U) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8 ph, pl;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        __bf16 hi, lo;
+                        split_bf(p[8 * ks + j], hi, lo);
+                        ph[j] = hi; pl[j] = lo;
+                    }
+                    const unsigned char* p2 = smb + 2 * T1B + r * T2P + (kk + 16 * ks + 4 * h) * 2;
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) {
+                        const unsigned char* q2 = p2 + cb * 32 * T2P;
+                        const bf16x4 h0 = *reinterpret_cast<const bf16x4*>(q2), h1 = *reinterpret_cast<const bf16x4*>(q2 + 16);
+                        const bf16x4 l0 = *reinterpret_cast<const bf16x4*>(q2 + T2B), l1 = *reinterpret_cast<const bf16x4*>(q2 + T2B + 16);
+                        const bf16x8 ah = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        const bf16x8 al = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        U[cb] = mfma_bf(ah, ph, U[cb]);
+                        U[cb] = mfma_bf(al, ph, U[cb]);
+                        U[cb] = mfma_bf(ah, pl, U[cb]);
+                    }
+                }
+            }
+        }
+    }
+    const float s_tot = s_run + __shfl_xor(s_run, 32, 64);
+    const int cnt_tot = cnt + __shfl_xor(cnt, 32, 64);
+    const int slot = blockIdx.y;
+    if (row_ok) {
+        if (h == 0) {
+            a.part_m[(int64_t)slot * a.R + row] = m_run;
+            a.part_s[(int64_t)slot * a.R + row] = s_tot;
+            a.part_cnt[(int64_t)slot * a.R + row] = cnt_tot;
+        }
+        if (WITH_U) {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg)
+                    a.part_U[((int64_t)slot * CH + cb * 32 + rho(reg, h)) * a.R + row] = U[cb][reg];
+        }
+    }
+}
+
 // Merge the per-split partials: lse, per-row loss, count of negatives above the
 // positive, d loss / d row (in the rows' own layout) and d loss / d extra logit.
 struct RowKeyFinArgs {
@@ -450,7 +624,7 @@ CP2_API int cp2_rowkey_num_splits(int R, int K) {
 CP2_API int cp2_rowkey_infonce_fwd(const float* rows, int RP, int64_t r_sn, int64_t r_sx, int64_t r_sc, int R,
                                    const float* keys, int K, const float* extras, int NE, float temperature,
                                    int nsplit, float* part_m, float* part_s, int32_t* part_cnt, float* part_U,
-                                   float* lnegT, int C, void* stream) {
+                                   float* lnegT, int precision, int C, void* stream) {
     if (!rows || !keys || !part_m || !part_s || !part_cnt) return CP2_ERR_NULL;
     if (NE > 0 && !extras) return CP2_ERR_NULL;
     if (R <= 0 || K <= 0 || RP <= 0 || nsplit <= 0 || NE < 0 || NE > 4 || !(temperature > 0.f)) return CP2_ERR_SHAPE;
@@ -470,6 +644,13 @@ CP2_API int cp2_rowkey_infonce_fwd(const float* rows, int RP, int64_t r_sn, int6
     }
     const dim3 grid(cp2_cdiv(R, 32 * WR), nsplit), block(256);
     const bool wu = part_U != nullptr;
+    if (precision == 1 && WR == 4) {   // split-bf16 on the matrix cores (many-row case only; otherwise the f32 kernel)
+        auto kfn = wu ? rowkey_fwd_bf16x3_kernel<true> : rowkey_fwd_bf16x3_kernel<false>;
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, BF_LDS);
+        if (e_ != hipSuccess) return (int)e_;
+        hipLaunchKernelGGL(kfn, grid, block, BF_LDS, cp2_stream(stream), a);
+        return cp2_launch_status();
+    }
 #define CP2_LAUNCH_RK(wr_, wk_, wu_)                                                                            \
     do {                                                                                                        \
         auto kfn = rowkey_fwd_kernel<wr_, wk_, wu_>;                                                            \

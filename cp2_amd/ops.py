@@ -259,12 +259,18 @@ class RowKeyResult:
 
 def rowkey_infonce(rows: torch.Tensor, row_layout: Tuple[int, int, int, int], R: int, keys: torch.Tensor,
                    extras: torch.Tensor, temperature: float, grad_scale: Optional[float],
-                   drows_like: Optional[torch.Tensor] = None, want_lneg: bool = False) -> RowKeyResult:
+                   drows_like: Optional[torch.Tensor] = None, want_lneg: bool = False,
+                   precision: str = "auto") -> RowKeyResult:
     """InfoNCE of R row vectors against the queue `keys` [C,K] with `extras` [R,NE] prepended
     (column 0 = positive).  row_layout = (RP, stride_n, stride_x, stride_c): element (c, r) of
     `rows` lives at (r//RP)*stride_n + (r%RP)*stride_x + c*stride_c.
     grad_scale None -> forward only; else drows (same layout, allocated like `drows_like` or
-    `rows`) and dE carry grad_scale * d(sum_r loss_r)/d(rows, extras)."""
+    `rows`) and dE carry grad_scale * d(sum_r loss_r)/d(rows, extras).
+    precision: "f32" (exact fp32 on the f32-input MFMA), "bf16x3" (split-bf16, logits within 3e-5, ~3x faster when
+    MFMA-bound) or "auto" = bf16x3 from 1024 rows up (the DenseCL per-pixel case), f32 below."""
+    if precision not in ("auto", "f32", "bf16x3"):
+        raise ValueError(f"precision {precision!r}")
+    prec = 1 if (precision == "bf16x3" or (precision == "auto" and R >= 1024)) else 0
     lib = _lib.load()
     C, K = keys.shape
     RP, sn, sx, sc = row_layout
@@ -284,7 +290,7 @@ def rowkey_infonce(rows: torch.Tensor, row_layout: Tuple[int, int, int, int], R:
     rc = lib.cp2_rowkey_infonce_fwd(rows.data_ptr(), RP, sn, sx, sc, R, _dev(keys, "keys", torch.float32), K,
                                     _dev(extras, "extras", torch.float32), NE, float(temperature), ns,
                                     part_m.data_ptr(), part_s.data_ptr(), part_cnt.data_ptr(), _opt(part_U, "part_U"),
-                                    _opt(out.lnegT, "lnegT"), C, _stream())
+                                    _opt(out.lnegT, "lnegT"), prec, C, _stream())
     _lib.check(rc, "cp2_rowkey_infonce_fwd")
     out.lse = torch.empty(R, dtype=torch.float32, device=dev)
     out.loss_rows = torch.empty(R, dtype=torch.float32, device=dev)

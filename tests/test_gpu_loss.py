@@ -238,3 +238,27 @@ def test_masked_quantiles_bit_exact_vs_torch():
     neg = ops.masked_quantiles(logits.to(DEV), P * P, 1, B, P * P, mask_a=ma.to(DEV), mask_b=mb.to(DEV), want=0)
     assert np.array_equal(pos.cpu().numpy(), st["positive"]["quartiles"].numpy(), equal_nan=True)
     assert np.array_equal(neg.cpu().numpy(), st["negative"]["quartiles"].numpy(), equal_nan=True)
+
+
+@pytest.mark.parametrize("R_rows,K", [(640, 8192), (200, 1000), (4096, 4096)])
+def test_rowkey_bf16x3_vs_oracle(R_rows, K):
+    """Split-bf16 mode of the rows-vs-queue kernel (hi*hi + hi*lo + lo*hi on bf16 MFMA): north_star's bound is fp32
+    logits within 1e-4; measured bounds asserted here: raw logits 3e-5, loss 5e-5, gradients 2e-4 * max|grad|."""
+    gen = torch.Generator().manual_seed(R_rows)
+    C, T = 128, 0.2
+    rows = torch.nn.functional.normalize(torch.randn(R_rows, C, generator=gen), dim=1)
+    queue = torch.nn.functional.normalize(torch.randn(C, K, generator=gen), dim=0)
+    pos = torch.rand(R_rows, generator=gen) * 2 - 1
+    r_cpu, p_cpu = rows.clone().requires_grad_(True), pos.clone().requires_grad_(True)
+    want = O.queue_infonce(r_cpu, p_cpu, queue, T)
+    want.backward()
+    got = ops.rowkey_infonce(rows.to(DEV), (1, C, 0, 1), R_rows, queue.to(DEV), pos.reshape(-1, 1).to(DEV), T,
+                             grad_scale=1.0 / R_rows, want_lneg=True, precision="bf16x3")
+    assert_close(got.lnegT.t(), rows @ queue, 3e-5, what="raw logits")
+    assert_close(got.loss, want.detach(), 5e-5, what="loss")
+    assert_close(got.drows, r_cpu.grad, 1e-9, 2e-4, "d rows")
+    assert_close(got.dE[:, 0], p_cpu.grad, 1e-9, 2e-4, "d pos")
+    exact = ops.rowkey_infonce(rows.to(DEV), (1, C, 0, 1), R_rows, queue.to(DEV), pos.reshape(-1, 1).to(DEV), T,
+                               grad_scale=1.0 / R_rows, precision="f32")
+    assert_close(exact.loss, want.detach(), 2e-5, what="f32 loss")
+    assert torch.equal(got.cnt_gt, exact.cnt_gt) or (got.cnt_gt - exact.cnt_gt).abs().max() <= 2

@@ -18,10 +18,11 @@ queue = torch.nn.functional.normalize(torch.randn(C, K, device=dev, generator=g)
 pos = torch.rand(b * S2, 1, device=dev, generator=g) * 2 - 1
 R = b * S2
 lay = (S2, C * S2, 1, S2)
-t_fwd = timeit(lambda: ops.rowkey_infonce(rows, lay, R, queue, pos, 0.2, None))
-t_all = timeit(lambda: ops.rowkey_infonce(rows, lay, R, queue, pos, 0.2, 1.0 / R))
 fl1 = 2.0 * R * C * K
-print(f"T19 R={R} K={K}: fwd-only {t_fwd:.3f} ms = {fl1 / t_fwd / 1e9:.1f} TFLOP/s ; fwd+grad {t_all:.3f} ms = {2 * fl1 / t_all / 1e9:.1f} TFLOP/s")
+for prec in ("f32", "bf16x3"):
+    t_fwd = timeit(lambda: ops.rowkey_infonce(rows, lay, R, queue, pos, 0.2, None, precision=prec))
+    t_all = timeit(lambda: ops.rowkey_infonce(rows, lay, R, queue, pos, 0.2, 1.0 / R, precision=prec))
+    print(f"T19 [{prec}] R={R} K={K}: fwd-only {t_fwd:.3f} ms = {fl1 / t_fwd / 1e9:.1f} TFLOP/s ; fwd+grad {t_all:.3f} ms = {2 * fl1 / t_all / 1e9:.1f} TFLOP/s (algorithmic)")
 # instance: config 2
 q_pos = torch.nn.functional.normalize(torch.randn(32, C, device=dev, generator=g), dim=1)
 ext = torch.rand(32, 1, device=dev, generator=g)

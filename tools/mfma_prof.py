@@ -8,8 +8,9 @@ rows = torch.nn.functional.normalize(torch.randn(b, C, S2, device=dev, generator
 queue = torch.nn.functional.normalize(torch.randn(C, K, device=dev, generator=g), dim=0)
 pos = torch.rand(b * S2, 1, device=dev, generator=g) * 2 - 1
 R = b * S2
-for _ in range(4):
-    ops.rowkey_infonce(rows, (S2, C * S2, 1, S2), R, queue, pos, 0.2, 1.0 / R)
+for prec in ("f32", "bf16x3"):
+    for _ in range(4):
+        ops.rowkey_infonce(rows, (S2, C * S2, 1, S2), R, queue, pos, 0.2, 1.0 / R, precision=prec)
 B, P = 8, 4096
 qd = torch.nn.functional.normalize(torch.randn(B, C, P, device=dev, generator=g), dim=1)
 kd = torch.nn.functional.normalize(torch.randn(B, C, P, device=dev, generator=g), dim=1)
