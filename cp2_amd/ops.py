@@ -14,7 +14,14 @@ import torch
 from . import _lib
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> int:
+    """Handle of the current HIP stream.  torch.cuda.current_stream().cuda_stream builds a Python Stream object per
+    call (~10 us, 1.3 ms per training step over all ops); the raw accessor returns the same handle in ~0.3 us."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
