@@ -130,7 +130,10 @@ def main():
     def one_step(i, timed):
         if timed:
             ev = EventPair()                                  # hipEvent_t pair attached to the kernel launch itself
-            ops.ema_flat_timed(model._flat_k, model._flat_q, model.momentum, ev)
+            if model._flat_k_bf16 is not None:
+                ops.ema_flat_shadow(model._flat_k, model._flat_q, model._flat_k_bf16, model.momentum, ev)
+            else:
+                ops.ema_flat_timed(model._flat_k, model._flat_q, model.momentum, ev)
             ema_events.append(ev)
         else:
             model._momentum_update_key_encoder()
@@ -160,7 +163,8 @@ def main():
 
     ema_ms = sum(ev.elapsed_ms() for ev in ema_events) / len(ema_events)
     n_param_floats = model._flat_q.numel()
-    ema_bytes = 12 * n_param_floats                      # read k, read q, write k: 12 algorithmic bytes per parameter slot
+    # read k, read q, write k (12 B) + the bf16 copy of the new key weights for the key encoder (2 B) per parameter slot
+    ema_bytes = (14 if model._flat_k_bf16 is not None else 12) * n_param_floats
     achieved = ema_bytes / (ema_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "ema_traffic.json")

@@ -225,6 +225,8 @@ class MODEL(nn.Module):
         self.correlation_ious, self.masked_correlation_ious = [], []
         self._flat_q = self._flat_k = None
         self.log_quartiles = True        # per-step quartile statistics of the reference (builder.py:1298,1399-1406), sort-free
+        self.key_weight_shadow = amp_dtype == torch.bfloat16   # EMA also emits bf16 key weights for the key encoder's convs
+        self._flat_k_bf16 = None
         self.ema_in_forward = True       # False: the caller runs _momentum_update_key_encoder() itself before forward
         self.overlap_key_branch = None   # key branch on a side stream: None = only when world size > 1 (no gain at N=1)
         self._side_stream = None
@@ -258,13 +260,26 @@ class MODEL(nn.Module):
             vq.copy_(p.data)
             vk.copy_(k.data)
             p.data, k.data = vq, vk
+        # bf16 shadow of the key weights (same element order), refreshed by every EMA launch: the key encoder's
+        # convolutions read it directly, so autocast launches no cast kernel per weight tensor
+        self._flat_k_bf16 = flat_k.to(torch.bfloat16) if self.key_weight_shadow else None
+        if self._flat_k_bf16 is not None:
+            from .encoder import Conv2d
+            by_param = {id(k): o for k, o in zip(pk, offs)}
+            for mod in self.encoder_k.modules():
+                if isinstance(mod, Conv2d) and id(mod.weight) in by_param:
+                    mod.shadow_weight = torch.as_strided(self._flat_k_bf16, mod.weight.shape, mod.weight.stride(),
+                                                         by_param[id(mod.weight)])
         self._flat_q, self._flat_k, self._flat_offsets = flat_q, flat_k, offs
 
     @torch.no_grad()
     def _momentum_update_key_encoder(self):
         """theta_k = theta_k*m + theta_q*(1-m) for every encoder parameter (reference builder.py:557-567)."""
         self.flatten_parameters()
-        ops.ema_flat(self._flat_k, self._flat_q, self.momentum)
+        if self._flat_k_bf16 is not None:
+            ops.ema_flat_shadow(self._flat_k, self._flat_q, self._flat_k_bf16, self.momentum)
+        else:
+            ops.ema_flat(self._flat_k, self._flat_q, self.momentum)
 
     def _key_stream(self):
         if self._side_stream is None:

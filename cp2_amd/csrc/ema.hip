@@ -22,8 +22,21 @@ __device__ __forceinline__ float4 ema4(float4 k, float4 q, float m, float om) {
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 constexpr int kEmaThreads = 128;
 
+// SHADOW: also store bf16(k_new) (round-to-nearest-even, what autocast's cast would produce) into a second flat
+// buffer with the same element order, so the key encoder's convolutions can take bf16 weights directly instead of
+// launching one cast kernel per weight tensor every step (+2 bytes written per parameter: 14 B instead of 12 B).
+typedef unsigned short u16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned short ema_f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+template <bool SHADOW>
 __global__ __launch_bounds__(kEmaThreads) void ema_flat_kernel(float* __restrict__ k, const float* __restrict__ q,
-                                                               int64_t n4, int64_t n, float m, float om) {
+                                                               unsigned short* __restrict__ kb, int64_t n4, int64_t n,
+                                                               float m, float om) {
     const int64_t i = (int64_t)blockIdx.x * kEmaThreads + threadIdx.x;
     if (i < n4) {
         f32x4_t* k4 = reinterpret_cast<f32x4_t*>(k);
@@ -34,27 +47,41 @@ __global__ __launch_bounds__(kEmaThreads) void ema_flat_kernel(float* __restrict
         r.x = ema1(kv.x, qv.x, m, om); r.y = ema1(kv.y, qv.y, m, om);
         r.z = ema1(kv.z, qv.z, m, om); r.w = ema1(kv.w, qv.w, m, om);
         __builtin_nontemporal_store(r, k4 + i);
+        if (SHADOW) {
+            u16x4_t b;
+            b.x = ema_f2bf(r.x); b.y = ema_f2bf(r.y); b.z = ema_f2bf(r.z); b.w = ema_f2bf(r.w);
+            reinterpret_cast<u16x4_t*>(kb)[i] = b;     // read again soon by the key encoder: default cache policy
+        }
     }
     if (blockIdx.x == 0) {  // tail (n not a multiple of 4)
-        for (int64_t j = n4 * 4 + threadIdx.x; j < n; j += kEmaThreads) k[j] = ema1(k[j], q[j], m, om);
+        for (int64_t j = n4 * 4 + threadIdx.x; j < n; j += kEmaThreads) {
+            const float r = ema1(k[j], q[j], m, om);
+            k[j] = r;
+            if (SHADOW) kb[j] = ema_f2bf(r);
+        }
     }
 }
 
-static int ema_flat_launch(float* k, const float* q, int64_t n, float m, float one_minus_m, hipEvent_t start,
-                           hipEvent_t stop, void* stream) {
+static int ema_flat_launch(float* k, const float* q, void* k_bf16, int64_t n, float m, float one_minus_m,
+                           hipEvent_t start, hipEvent_t stop, void* stream) {
     if (!k || !q) return CP2_ERR_NULL;
     if (n <= 0) return CP2_ERR_SHAPE;
-    if (!cp2_aligned16(k) || !cp2_aligned16(q)) return CP2_ERR_ALIGN;
+    if (!cp2_aligned16(k) || !cp2_aligned16(q) || (k_bf16 && (reinterpret_cast<uintptr_t>(k_bf16) & 7u))) return CP2_ERR_ALIGN;
     const int64_t n4 = n / 4;
     const int64_t blocks = n4 > 0 ? (n4 + kEmaThreads - 1) / kEmaThreads : 1;
     if (blocks > 0x7fffffffLL) return CP2_ERR_UNSUPPORTED;
-    hipExtLaunchKernelGGL(ema_flat_kernel, dim3((unsigned)blocks), dim3(kEmaThreads), 0, cp2_stream(stream), start, stop,
-                          0, k, q, n4, n, m, one_minus_m);
+    unsigned short* kb = static_cast<unsigned short*>(k_bf16);
+    if (kb)
+        hipExtLaunchKernelGGL(ema_flat_kernel<true>, dim3((unsigned)blocks), dim3(kEmaThreads), 0, cp2_stream(stream), start,
+                              stop, 0, k, q, kb, n4, n, m, one_minus_m);
+    else
+        hipExtLaunchKernelGGL(ema_flat_kernel<false>, dim3((unsigned)blocks), dim3(kEmaThreads), 0, cp2_stream(stream), start,
+                              stop, 0, k, q, kb, n4, n, m, one_minus_m);
     return cp2_launch_status();
 }
 
 CP2_API int cp2_ema_flat(float* k, const float* q, int64_t n, float m, float one_minus_m, void* stream) {
-    return ema_flat_launch(k, q, n, m, one_minus_m, nullptr, nullptr, stream);
+    return ema_flat_launch(k, q, nullptr, n, m, one_minus_m, nullptr, nullptr, stream);
 }
 
 // Same launch with a pair of caller-owned hipEvent_t that bracket exactly this kernel
@@ -62,7 +89,15 @@ CP2_API int cp2_ema_flat(float* k, const float* q, int64_t n, float m, float one
 CP2_API int cp2_ema_flat_timed(float* k, const float* q, int64_t n, float m, float one_minus_m, void* start_event,
                                void* stop_event, void* stream) {
     if (!start_event || !stop_event) return CP2_ERR_NULL;
-    return ema_flat_launch(k, q, n, m, one_minus_m, reinterpret_cast<hipEvent_t>(start_event),
+    return ema_flat_launch(k, q, nullptr, n, m, one_minus_m, reinterpret_cast<hipEvent_t>(start_event),
+                           reinterpret_cast<hipEvent_t>(stop_event), stream);
+}
+
+// EMA + bf16 shadow copy of the updated key weights (k_bf16: n bf16 values, 8-byte aligned); events may be NULL.
+CP2_API int cp2_ema_flat_shadow(float* k, const float* q, void* k_bf16, int64_t n, float m, float one_minus_m,
+                                void* start_event, void* stop_event, void* stream) {
+    if (!k_bf16) return CP2_ERR_NULL;
+    return ema_flat_launch(k, q, k_bf16, n, m, one_minus_m, reinterpret_cast<hipEvent_t>(start_event),
                            reinterpret_cast<hipEvent_t>(stop_event), stream);
 }
 

@@ -80,12 +80,26 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
         super()._save_to_state_dict(destination, prefix, keep_vars)
 
 
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d that uses `shadow_weight` -- a bf16 copy of `weight` kept current by someone else (the EMA kernel
+    writes it for the key encoder) -- when the input is bf16, so autocast launches no per-tensor cast kernel."""
+
+    shadow_weight = None
+
+    def forward(self, x):
+        w = self.shadow_weight
+        if w is not None and x.dtype == torch.bfloat16:
+            b = self.bias.to(torch.bfloat16) if self.bias is not None else None
+            return self._conv_forward(x, w, b)
+        return super().forward(x)
+
+
 class ConvBNAct(nn.Module):
     """conv -> BN -> ReLU with mmcv ConvModule's sub-module names (`conv`, `bn`, `activate`)."""
 
     def __init__(self, cin, cout, k, padding=0, dilation=1, norm=True):
         super().__init__()
-        self.conv = nn.Conv2d(cin, cout, k, padding=padding, dilation=dilation, bias=not norm)
+        self.conv = Conv2d(cin, cout, k, padding=padding, dilation=dilation, bias=not norm)
         if norm:
             self.bn = FusedBatchNorm2d(cout)
         self.activate = nn.ReLU(inplace=True)
@@ -99,7 +113,7 @@ class ConvBNAct(nn.Module):
 
 
 def _downsample(cin, cout, stride):
-    return nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride, bias=False), FusedBatchNorm2d(cout))
+    return nn.Sequential(Conv2d(cin, cout, 1, stride=stride, bias=False), FusedBatchNorm2d(cout))
 
 
 class BasicBlock(nn.Module):
@@ -107,9 +121,9 @@ class BasicBlock(nn.Module):
 
     def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None):
         super().__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)
+        self.conv1 = Conv2d(inplanes, planes, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)
         self.bn1 = FusedBatchNorm2d(planes)
-        self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
+        self.conv2 = Conv2d(planes, planes, 3, padding=1, bias=False)
         self.bn2 = FusedBatchNorm2d(planes)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
@@ -125,11 +139,11 @@ class Bottleneck(nn.Module):
 
     def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None):
         super().__init__()   # style='pytorch': the stride sits on the 3x3 conv
-        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.conv1 = Conv2d(inplanes, planes, 1, bias=False)
         self.bn1 = FusedBatchNorm2d(planes)
-        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)
+        self.conv2 = Conv2d(planes, planes, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)
         self.bn2 = FusedBatchNorm2d(planes)
-        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.conv3 = Conv2d(planes, planes * 4, 1, bias=False)
         self.bn3 = FusedBatchNorm2d(planes * 4)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
@@ -158,7 +172,7 @@ class ResNet(nn.Module):
         block, blocks = _ARCH[depth]
         self.depth, self.out_indices, self.norm_eval = depth, tuple(out_indices), norm_eval
         self.zero_init_residual, self.init_cfg = zero_init_residual, init_cfg
-        self.conv1 = nn.Conv2d(in_channels, stem_channels, 7, stride=2, padding=3, bias=False)
+        self.conv1 = Conv2d(in_channels, stem_channels, 7, stride=2, padding=3, bias=False)
         self.bn1 = FusedBatchNorm2d(stem_channels)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
@@ -235,8 +249,8 @@ class _DecodeHead(nn.Module):
 
     def _add_contrast(self):
         if self.contrast:     # aspp_head.py:93-97 / fcn_head.py:75-79: the 128-d 1x1-conv projector
-            self.contrast_conv = nn.Sequential(nn.Conv2d(self.channels, self.channels, 1), nn.ReLU(),
-                                               nn.Conv2d(self.channels, 128, 1))
+            self.contrast_conv = nn.Sequential(Conv2d(self.channels, self.channels, 1), nn.ReLU(),
+                                               Conv2d(self.channels, 128, 1))
             # conv_seg never receives a gradient on the contrast path; freezing it keeps its
             # state-dict entry while letting DDP run without find_unused_parameters.
             self.conv_seg.requires_grad_(False)

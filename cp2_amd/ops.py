@@ -129,6 +129,18 @@ def ema_flat(k: torch.Tensor, q: torch.Tensor, m: float) -> None:
     _lib.check(rc, "cp2_ema_flat")
 
 
+def ema_flat_shadow(k: torch.Tensor, q: torch.Tensor, k_bf16: torch.Tensor, m: float, events=None) -> None:
+    """ema_flat that also stores bf16(k_new) into `k_bf16` (same element order); optional hipevents.EventPair."""
+    lib = _lib.load()
+    if k_bf16.numel() != k.numel():
+        raise ValueError("ema_flat_shadow: shadow buffer differs in size")
+    m32, om32 = ema_scalars(m)
+    rc = lib.cp2_ema_flat_shadow(_dev(k, "k", torch.float32), _dev(q, "q", torch.float32), _dev(k_bf16, "k_bf16", torch.bfloat16),
+                                 k.numel(), m32, om32, events.start if events else None, events.stop if events else None,
+                                 _stream())
+    _lib.check(rc, "cp2_ema_flat_shadow")
+
+
 def ema_flat_timed(k: torch.Tensor, q: torch.Tensor, m: float, events) -> None:
     """ema_flat with an `hipevents.EventPair` bracketing exactly this kernel."""
     lib = _lib.load()

@@ -75,6 +75,10 @@ int cp2_ema_flat(float* k, const float* q, int64_t n, float m, float one_minus_m
  * (for hipEventElapsedTime after the stream has been synchronised). */
 int cp2_ema_flat_timed(float* k, const float* q, int64_t n, float m, float one_minus_m, void* start_event,
                        void* stop_event, void* stream);
+/* EMA that also writes k_bf16[i] = bf16(k[i]) (round to nearest even) for the updated values: n bf16, 8-byte aligned.
+ * Lets the key encoder consume bf16 weights without per-tensor cast kernels.  Events as in _timed, or NULL. */
+int cp2_ema_flat_shadow(float* k, const float* q, void* k_bf16, int64_t n, float m, float one_minus_m,
+                        void* start_event, void* stop_event, void* stream);
 /* Multi-tensor form: device tables of n_tensors pointers/sizes, plus a device chunk
  * table built by the caller: chunk c covers elements [chunk_off[c], chunk_off[c]+chunk_len[c])
  * of tensor chunk_tensor[c].  One launch for the whole encoder. */

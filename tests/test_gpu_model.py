@@ -140,3 +140,33 @@ def test_flatten_preserves_channels_last_and_values():
     model._momentum_update_key_encoder()
     for p, w_ in zip(model.encoder_k.parameters(), want):
         assert torch.equal(p.detach().cpu(), w_)
+
+
+def test_key_weight_shadow_is_exact_and_used():
+    """The EMA's bf16 shadow of the key weights equals casting the fp32 weights, and the key encoder gives the same
+    output with and without it."""
+    model = small_model(amp_dtype=torch.bfloat16, channels_last=True)
+    model.encoder_q.to(memory_format=torch.channels_last)
+    model.encoder_k.to(memory_format=torch.channels_last)
+    for p in model.encoder_q.parameters():
+        p.data.add_(0.003 * torch.randn_like(p))
+    model._momentum_update_key_encoder()
+    assert model._flat_k_bf16 is not None
+    assert torch.equal(model._flat_k_bf16, model._flat_k.to(torch.bfloat16))
+    conv = model.encoder_k.backbone.layer2[0].conv2
+    assert conv.shadow_weight is not None and torch.equal(conv.shadow_weight, conv.weight.to(torch.bfloat16))
+    assert conv.shadow_weight.stride() == conv.weight.stride()
+    x = torch.rand(4, 3, 64, 64, device=DEV).contiguous(memory_format=torch.channels_last)
+    model.encoder_k.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        y1 = model.encoder_k(x)
+        from cp2_amd.encoder import Conv2d
+        saved = {}
+        for m in model.encoder_k.modules():
+            if isinstance(m, Conv2d):
+                saved[m] = m.shadow_weight
+                m.shadow_weight = None
+        y2 = model.encoder_k(x)
+        for m, w in saved.items():
+            m.shadow_weight = w
+    assert torch.equal(y1, y2)
