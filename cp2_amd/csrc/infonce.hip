@@ -320,8 +320,82 @@ __device__ __forceinline__ void tile_store_bf(unsigned char* __restrict__ sm, co
     }
 }
 
-template <bool WITH_U>
-__global__ __launch_bounds__(256, 2) void rowkey_fwd_bf16x3_kernel(RowKeyArgs a) {
+// Pre-split form of the key operand for the bf16x3 kernel: the fp32 queue [C][K] is converted ONCE per call into
+// four bf16 arrays -- hi/lo, key-major [K][C] (product 1) and channel-major [C][K] (product 2) -- so the main kernel
+// fills its LDS images with 16-byte copies.  (Doing the conversion inside the main kernel repeated it for every one
+// of the 49 row blocks and built the key-major image with 2-byte LDS writes that were 8-way bank conflicted: PMC
+// SQ_LDS_BANK_CONFLICT was 60 % of SQ_LDS_IDX_ACTIVE.)   split = [qT_hi | qT_lo | q_hi | q_lo], each C*K bf16.
+__global__ __launch_bounds__(256) void keys_split_kernel(const float* __restrict__ keys, int K, __bf16* __restrict__ split) {
+    __shared__ float tile[64][CH + 1];                    // [key][c]
+    const int k0 = blockIdx.x * 64, tid = threadIdx.x;
+    const int64_t CK = (int64_t)CH * K;
+    __bf16 *qth = split, *qtl = split + CK, *qh = split + 2 * CK, *ql = split + 3 * CK;
+    for (int e = tid; e < CH * 64; e += 256) {            // coalesced along keys
+        const int c = e / 64, j = e % 64;
+        const float v = (k0 + j < K) ? keys[(int64_t)c * K + k0 + j] : 0.f;
+        tile[j][c] = v;
+        if (k0 + j < K) {
+            __bf16 hi, lo;
+            split_bf(v, hi, lo);
+            qh[(int64_t)c * K + k0 + j] = hi;
+            ql[(int64_t)c * K + k0 + j] = lo;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < CH * 64; e += 256) {            // coalesced along channels
+        const int j = e / CH, c = e % CH;
+        if (k0 + j < K) {
+            __bf16 hi, lo;
+            split_bf(tile[j][c], hi, lo);
+            qth[(int64_t)(k0 + j) * CH + c] = hi;
+            qtl[(int64_t)(k0 + j) * CH + c] = lo;
+        }
+    }
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// LDS images from the pre-split arrays: 16-byte global loads, ds_write_b128 (image 1) / 2 x ds_write_b64 (image 2).
+__device__ __forceinline__ void tile_fill_presplit(unsigned char* __restrict__ sm, const __bf16* __restrict__ split, int K,
+                                                   int k0, int k_end, int tid) {
+    const int64_t CK = (int64_t)CH * K;
+    u32x4 v1[8], v2[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                          // image 1: 64 key rows x 16 chunks, hi then lo
+        const int e = tid + i * 256, key = e >> 4, q = e & 15;
+        const bool ok = k0 + key < k_end;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        v1[i] = ok ? *reinterpret_cast<const u32x4*>(split + (int64_t)(k0 + key) * CH + q * 8) : z;
+        v1[4 + i] = ok ? *reinterpret_cast<const u32x4*>(split + CK + (int64_t)(k0 + key) * CH + q * 8) : z;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                          // image 2: 128 channel rows x 8 chunks of 8 keys
+        const int e = tid + i * 256, c = e >> 3, q = e & 7;
+        const bool ok = k0 + q * 8 < k_end;                // K % 8 == 0 and k_end % 8 == 0: a chunk is all-or-nothing
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        v2[i] = ok ? *reinterpret_cast<const u32x4*>(split + 2 * CK + (int64_t)c * K + k0 + q * 8) : z;
+        v2[4 + i] = ok ? *reinterpret_cast<const u32x4*>(split + 3 * CK + (int64_t)c * K + k0 + q * 8) : z;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + i * 256, key = e >> 4, q = e & 15;
+        *reinterpret_cast<u32x4*>(sm + key * T1P + q * 16) = v1[i];
+        *reinterpret_cast<u32x4*>(sm + T1B + key * T1P + q * 16) = v1[4 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + i * 256, c = e >> 3, q = e & 7;
+        unsigned char* d = sm + 2 * T1B + c * T2P + q * 16;
+        *reinterpret_cast<u32x2*>(d) = (u32x2){v2[i].x, v2[i].y};
+        *reinterpret_cast<u32x2*>(d + 8) = (u32x2){v2[i].z, v2[i].w};
+        *reinterpret_cast<u32x2*>(d + T2B) = (u32x2){v2[4 + i].x, v2[4 + i].y};
+        *reinterpret_cast<u32x2*>(d + T2B + 8) = (u32x2){v2[4 + i].z, v2[4 + i].w};
+    }
+}
+
+template <bool WITH_U, bool PRESPLIT>
+__global__ __launch_bounds__(256, 2) void rowkey_fwd_bf16x3_kernel(RowKeyArgs a, const __bf16* __restrict__ ksplit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -352,12 +426,16 @@ __global__ __launch_bounds__(256, 2) void rowkey_fwd_bf16x3_kernel(RowKeyArgs a)
     const int k_end = min(a.K, k_begin + a.keys_per_split);
     const bool vec_ok = (a.K % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.keys) & 15u) == 0);
     TileRegs<BKT> rg;
-    tile_load<BKT>(rg, a.keys, a.K, k_begin, k_end, tid, vec_ok);
+    if (!PRESPLIT) tile_load<BKT>(rg, a.keys, a.K, k_begin, k_end, tid, vec_ok);
     for (int k0 = k_begin; k0 < k_end; k0 += BKT) {
         __syncthreads();
-        tile_store_bf(smb, rg, tid);
+        if (PRESPLIT) {
+            tile_fill_presplit(smb, ksplit, a.K, k0, k_end, tid);
+        } else {
+            tile_store_bf(smb, rg, tid);
+        }
         __syncthreads();
-        if (k0 + BKT < k_end) tile_load<BKT>(rg, a.keys, a.K, k0 + BKT, k_end, tid, vec_ok);
+        if (!PRESPLIT && k0 + BKT < k_end) tile_load<BKT>(rg, a.keys, a.K, k0 + BKT, k_end, tid, vec_ok);
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int kk = sub * 32;
@@ -624,7 +702,7 @@ CP2_API int cp2_rowkey_num_splits(int R, int K) {
 CP2_API int cp2_rowkey_infonce_fwd(const float* rows, int RP, int64_t r_sn, int64_t r_sx, int64_t r_sc, int R,
                                    const float* keys, int K, const float* extras, int NE, float temperature,
                                    int nsplit, float* part_m, float* part_s, int32_t* part_cnt, float* part_U,
-                                   float* lnegT, int precision, int C, void* stream) {
+                                   float* lnegT, int precision, void* keys_split, int C, void* stream) {
     if (!rows || !keys || !part_m || !part_s || !part_cnt) return CP2_ERR_NULL;
     if (NE > 0 && !extras) return CP2_ERR_NULL;
     if (R <= 0 || K <= 0 || RP <= 0 || nsplit <= 0 || NE < 0 || NE > 4 || !(temperature > 0.f)) return CP2_ERR_SHAPE;
@@ -645,10 +723,18 @@ CP2_API int cp2_rowkey_infonce_fwd(const float* rows, int RP, int64_t r_sn, int6
     const dim3 grid(cp2_cdiv(R, 32 * WR), nsplit), block(256);
     const bool wu = part_U != nullptr;
     if (precision == 1 && WR == 4) {   // split-bf16 on the matrix cores (many-row case only; otherwise the f32 kernel)
-        auto kfn = wu ? rowkey_fwd_bf16x3_kernel<true> : rowkey_fwd_bf16x3_kernel<false>;
+        __bf16* ks = static_cast<__bf16*>(keys_split);
+        const bool pre = ks != nullptr && K % 8 == 0 && kps % 8 == 0 && cp2_aligned16(ks);
+        if (pre) {
+            hipLaunchKernelGGL(keys_split_kernel, dim3(cp2_cdiv(K, 64)), dim3(256), 0, cp2_stream(stream), keys, K, ks);
+            int rc0 = cp2_launch_status();
+            if (rc0) return rc0;
+        }
+        auto kfn = pre ? (wu ? rowkey_fwd_bf16x3_kernel<true, true> : rowkey_fwd_bf16x3_kernel<false, true>)
+                       : (wu ? rowkey_fwd_bf16x3_kernel<true, false> : rowkey_fwd_bf16x3_kernel<false, false>);
         hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, BF_LDS);
         if (e_ != hipSuccess) return (int)e_;
-        hipLaunchKernelGGL(kfn, grid, block, BF_LDS, cp2_stream(stream), a);
+        hipLaunchKernelGGL(kfn, grid, block, BF_LDS, cp2_stream(stream), a, pre ? ks : nullptr);
         return cp2_launch_status();
     }
 #define CP2_LAUNCH_RK(wr_, wk_, wu_)                                                                            \

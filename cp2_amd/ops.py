@@ -279,7 +279,7 @@ class RowKeyResult:
 def rowkey_infonce(rows: torch.Tensor, row_layout: Tuple[int, int, int, int], R: int, keys: torch.Tensor,
                    extras: torch.Tensor, temperature: float, grad_scale: Optional[float],
                    drows_like: Optional[torch.Tensor] = None, want_lneg: bool = False,
-                   precision: str = "auto") -> RowKeyResult:
+                   precision: str = "auto", presplit: bool = True) -> RowKeyResult:
     """InfoNCE of R row vectors against the queue `keys` [C,K] with `extras` [R,NE] prepended
     (column 0 = positive).  row_layout = (RP, stride_n, stride_x, stride_c): element (c, r) of
     `rows` lives at (r//RP)*stride_n + (r%RP)*stride_x + c*stride_c.
@@ -304,12 +304,14 @@ def rowkey_infonce(rows: torch.Tensor, row_layout: Tuple[int, int, int, int], R:
     part_U = torch.empty((ns, C, R), dtype=torch.float32, device=dev) if want_grad else None
     out = RowKeyResult()
     out.lnegT = torch.empty((K, R), dtype=torch.float32, device=dev) if want_lneg else None
+    # bf16x3: the queue's hi/lo split in both layouts, written once per call by a prep kernel (4*C*K bf16)
+    ksplit = torch.empty(4 * C * K, dtype=torch.bfloat16, device=dev) if (prec == 1 and R > 64 and K % 8 == 0 and presplit) else None
     if not rows.is_cuda or rows.dtype != torch.float32:
         raise _lib.Cp2LibraryError("rowkey_infonce: rows must be a float32 GPU tensor")
     rc = lib.cp2_rowkey_infonce_fwd(rows.data_ptr(), RP, sn, sx, sc, R, _dev(keys, "keys", torch.float32), K,
                                     _dev(extras, "extras", torch.float32), NE, float(temperature), ns,
                                     part_m.data_ptr(), part_s.data_ptr(), part_cnt.data_ptr(), _opt(part_U, "part_U"),
-                                    _opt(out.lnegT, "lnegT"), prec, C, _stream())
+                                    _opt(out.lnegT, "lnegT"), prec, _opt(ksplit, "keys_split"), C, _stream())
     _lib.check(rc, "cp2_rowkey_infonce_fwd")
     out.lse = torch.empty(R, dtype=torch.float32, device=dev)
     out.loss_rows = torch.empty(R, dtype=torch.float32, device=dev)

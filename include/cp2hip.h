@@ -124,12 +124,14 @@ int cp2_feat_bwd(const float* dense, const float* inv_norm, const float* mask, c
  * part_cnt [nsplit,R] int32, part_U [nsplit,C,R] (NULL: no gradient), lnegT [K,R] raw logits or NULL.
  * precision 0: f32-input MFMA (exact fp32 fma chains, logits within ~1e-6 of the reference);
  * precision 1: split-bf16 (hi*hi + hi*lo + lo*hi on bf16 MFMA, fp32 accumulate; logits within 3e-5) -- used when
- *              R > 64, otherwise the f32 kernel runs regardless. */
+ *              R > 64, otherwise the f32 kernel runs regardless.  keys_split: NULL, or a workspace of 4*C*K bf16
+ *              (16-byte aligned, K % 8 == 0) that receives the hi/lo split of the queue in both layouts once per call;
+ *              with it the main kernel fills LDS by 16-byte copies instead of converting in every row block. */
 int cp2_rowkey_num_splits(int R, int K);
 int cp2_rowkey_infonce_fwd(const float* rows, int RP, int64_t r_sn, int64_t r_sx, int64_t r_sc, int R,
                            const float* keys, int K, const float* extras, int NE, float temperature,
                            int nsplit, float* part_m, float* part_s, int32_t* part_cnt, float* part_U,
-                           float* lnegT, int precision, int C, void* stream);
+                           float* lnegT, int precision, void* keys_split, int C, void* stream);
 /* Merge the splits: lse[R], loss_rows[R], cnt_gt[R] (# negatives whose logit exceeds the positive),
  * drows (same addressing as rows, with d_* strides; NULL: skip) = grad_scale * d sum_r loss_r / d rows,
  * dE [R,NE] likewise (may be NULL), loss_mean[1] = mean_r loss_r (may be NULL). */

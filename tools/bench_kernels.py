@@ -19,10 +19,10 @@ pos = torch.rand(b * S2, 1, device=dev, generator=g) * 2 - 1
 R = b * S2
 lay = (S2, C * S2, 1, S2)
 fl1 = 2.0 * R * C * K
-for prec in ("f32", "bf16x3"):
-    t_fwd = timeit(lambda: ops.rowkey_infonce(rows, lay, R, queue, pos, 0.2, None, precision=prec))
-    t_all = timeit(lambda: ops.rowkey_infonce(rows, lay, R, queue, pos, 0.2, 1.0 / R, precision=prec))
-    print(f"T19 [{prec}] R={R} K={K}: fwd-only {t_fwd:.3f} ms = {fl1 / t_fwd / 1e9:.1f} TFLOP/s ; fwd+grad {t_all:.3f} ms = {2 * fl1 / t_all / 1e9:.1f} TFLOP/s (algorithmic)")
+for prec, pre in (("f32", False), ("bf16x3", False), ("bf16x3", True)):
+    t_fwd = timeit(lambda: ops.rowkey_infonce(rows, lay, R, queue, pos, 0.2, None, precision=prec, presplit=pre))
+    t_all = timeit(lambda: ops.rowkey_infonce(rows, lay, R, queue, pos, 0.2, 1.0 / R, precision=prec, presplit=pre))
+    print(f"T19 [{prec}{' presplit' if pre else ''}] R={R} K={K}: fwd-only {t_fwd:.3f} ms = {fl1 / t_fwd / 1e9:.1f} TFLOP/s ; fwd+grad {t_all:.3f} ms = {2 * fl1 / t_all / 1e9:.1f} TFLOP/s (algorithmic)")
 # instance: config 2
 q_pos = torch.nn.functional.normalize(torch.randn(32, C, device=dev, generator=g), dim=1)
 ext = torch.rand(32, 1, device=dev, generator=g)
