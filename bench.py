@@ -168,9 +168,11 @@ def main():
     achieved = ema_bytes / (ema_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "ema_traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath):   # PMC result of the same kernel on the same buffer size (tools/ema_only.py); else null
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            if int(tj.get("algorithmic_bytes_per_launch", -1)) == int(ema_bytes):
+                traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     imgs = b * world * args.steps
