@@ -141,6 +141,22 @@ def queue_infonce(rows: torch.Tensor, pos: torch.Tensor, queue: torch.Tensor, te
     return _QueueInfoNCEFn.apply(rows, pos.float(), queue, float(temperature), layout, R)
 
 
+def densecl_local_positives(q_embed, k_embed, q_local, k_local, ids_q, ids_k, lmbd_coordinate: float = 0.0):
+    """Positive score of every query pixel for the DenseCL local loss (reference builder.py:818-855):
+    local similarity with the key pixel that maximises the BACKBONE similarity; where the two id maps overlap it is
+    mixed with the summed local similarity over id-matching key pixels.  Inputs are channel-normalised (b, C, S2);
+    ids are (b, S2).  Returns (pos (b, S2), arg-max index (b, S2)).  Plain batched GEMMs (hipBLASLt) + gather."""
+    best = torch.bmm(q_embed.transpose(1, 2), k_embed).argmax(dim=2)
+    local_sim = torch.bmm(q_local.transpose(1, 2), k_local)
+    pos = torch.gather(local_sim, 2, best.unsqueeze(2)).squeeze(2)
+    if lmbd_coordinate > 0:
+        corr = ids_q[:, :, None] == ids_k[:, None, :]
+        overlap = corr.any(-1)
+        coord = (local_sim * corr).sum(-1)
+        pos = torch.where(overlap, pos * (1 - lmbd_coordinate) + coord * lmbd_coordinate, pos)
+    return pos, best
+
+
 class MODEL(nn.Module):
     def __init__(self, cfg, rank, dim=128, K=65536, m=0.999, instance_logits_temp=0.2, pretrain_from_scratch=False,
                  include_background=False, lmbd_cp2_dense_loss=0.2, lmbd_pixel_corr_weight=1,
@@ -427,15 +443,7 @@ class MODEL(nn.Module):
             return queue_infonce(qg, (qg * kg).sum(1), self.queue, self.temp_global)
 
         def local_loss(q_embed, k_embed, q_local, k_local, ids_q, ids_k):
-            # positives by backbone-feature arg-max, optionally mixed with coordinate matches (builder.py:818-855)
-            best = torch.bmm(q_embed.transpose(1, 2), k_embed).argmax(dim=2)
-            local_sim = torch.bmm(q_local.transpose(1, 2), k_local)
-            pos = torch.gather(local_sim, 2, best.unsqueeze(2)).squeeze(2)
-            if self.lmbd_coordinate > 0:
-                corr = ids_q[:, :, None] == ids_k[:, None, :]
-                overlap = corr.any(-1)
-                coord = (local_sim * corr).sum(-1)
-                pos = torch.where(overlap, pos * (1 - self.lmbd_coordinate) + coord * self.lmbd_coordinate, pos)
+            pos, _ = densecl_local_positives(q_embed, k_embed, q_local, k_local, ids_q, ids_k, self.lmbd_coordinate)
             return queue_infonce(q_local, pos.reshape(-1), self.queue2, self.temp_local)
 
         eq, lq, gq = query_features(img_a)

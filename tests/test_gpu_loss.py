@@ -262,3 +262,25 @@ def test_rowkey_bf16x3_vs_oracle(R_rows, K):
                                grad_scale=1.0 / R_rows, precision="f32")
     assert_close(exact.loss, want.detach(), 2e-5, what="f32 loss")
     assert torch.equal(got.cnt_gt, exact.cnt_gt) or (got.cnt_gt - exact.cnt_gt).abs().max() <= 2
+
+
+@pytest.mark.parametrize("name", ["densecl_b2_128_k64", "densecl_b2_96_k64_coord"])
+def test_densecl_local_positives_and_losses_golden(golden_dir, name):
+    """T18 + T19 of forward_densecl on the reference's recorded tensors (builder.py:808-910, :760-772)."""
+    from cp2_amd import builder
+    g = load(golden_dir, name)
+    tg, tl, lmbd, lc = [float(v) for v in g["cfg_f"]]
+    b = g["q_local"].shape[0]
+    pos, best = builder.densecl_local_positives(G(g["q_embed"]), G(g["k_embed"]), G(g["q_local"]), G(g["k_local"]),
+                                                G(g["q_pixel_ids"]).reshape(b, -1), G(g["k_pixel_ids"]).reshape(b, -1), lc)
+    assert np.array_equal(best.cpu().numpy(), g["pos_global_k_idx"])
+    assert_close(pos.reshape(-1, 1), g["pos_local"], 3e-6, what="pos_local")
+    ql = G(g["q_local"]).requires_grad_(True)
+    loss_local = builder.queue_infonce(ql, pos.reshape(-1).detach(), G(g["queue2_before"]), tl)
+    loss_local.backward()
+    assert_close(loss_local, g["loss_local"], 2e-5, what="loss_local")
+    qg = G(g["q_global"])
+    loss_global = builder.queue_infonce(qg, (qg * G(g["k_global"])).sum(1), G(g["queue_before"]), tg)
+    assert_close(loss_global, g["loss_global"], 2e-5, what="loss_global")
+    assert_close((1 - lmbd) * loss_global + lmbd * loss_local, g["loss"], 2e-5, what="loss")
+    assert torch.isfinite(ql.grad).all() and float(ql.grad.abs().max()) > 0
