@@ -246,6 +246,8 @@ class MODEL(nn.Module):
         self.ema_in_forward = True       # False: the caller runs _momentum_update_key_encoder() itself before forward
         self.overlap_key_branch = None   # key branch on a side stream: None = only when world size > 1 (no gain at N=1)
         self._side_stream = None
+        self.key_forward_graph = True    # replay the (gradient-free) key encoder forward from a hipGraph after warm-up
+        self._key_graph = None
         self._pending_logs = []          # device scalars waiting for one batched device->host copy
         self.sync_logs_every = 0         # 0: only when flush_logs() / on_train_epoch_end() is called
 
@@ -296,6 +298,38 @@ class MODEL(nn.Module):
             ops.ema_flat_shadow(self._flat_k, self._flat_q, self._flat_k_bf16, self.momentum)
         else:
             ops.ema_flat(self._flat_k, self._flat_q, self.momentum)
+
+    def _encode_key(self, img):
+        """Key encoder forward (reference builder.py:1276).  No autograd, fixed shapes, static weights addresses
+        (the flat buffers): replayed from a hipGraph (engine.ForwardGraph) so its ~280 launches cost no host time."""
+        if not self.key_forward_graph or not img.is_cuda:
+            return self._encode(self.encoder_k, img)
+        if self._key_graph is None:
+            from .encoder import FusedBatchNorm2d
+            from .engine import ForwardGraph
+            bns = [m for m in self.encoder_k.modules() if isinstance(m, FusedBatchNorm2d)]
+
+            def fwd(x):
+                # a captured call does not execute: take back the lazy num_batches_tracked ticks it made
+                capturing = torch.cuda.is_current_stream_capturing()
+                before = [m._pending_batches for m in bns] if capturing else None
+                out = self._encode(self.encoder_k, x)
+                if capturing:
+                    fwd.fused = [m for m, b in zip(bns, before) if m._pending_batches != b]
+                    for m, b in zip(bns, before):
+                        m._pending_batches = b
+                return out
+
+            fwd.fused = []
+
+            def tick():
+                for m in fwd.fused:
+                    m._pending_batches += 1
+
+            self._key_graph = ForwardGraph(fwd, warmup=3, on_replay=tick)
+        # the graph reads the key weights where flatten_parameters() put them: a new home invalidates it
+        return self._key_graph(img, tag=(self._flat_k.data_ptr() if self._flat_k is not None else None,
+                                         self.encoder_k.training, torch.is_grad_enabled()))
 
     def _key_stream(self):
         if self._side_stream is None:
@@ -377,7 +411,7 @@ class MODEL(nn.Module):
             if self.ema_in_forward:
                 self._momentum_update_key_encoder()
             img_b, idx_unshuffle = self._batch_shuffle_ddp(img_b, idx_shuffle)
-            k = self._encode(self.encoder_k, img_b)
+            k = self._encode_key(img_b)
             k = self._batch_unshuffle_ddp(k, idx_unshuffle)
         q = self._encode(self.encoder_q, img_a).float()                          # queries: b x C x h x w
         if side is not cur:

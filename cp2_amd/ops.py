@@ -413,17 +413,20 @@ def masked_quantiles(x: torch.Tensor, stride_row: int, stride_elem: int, R: int,
 
 # ---------------------------------------------------------------- encoder fast path: fused BatchNorm
 def bn_supported(x: torch.Tensor) -> bool:
-    """channels-last bf16 GPU activations with C = 8 * 2^k <= 2048."""
+    """channels-last bf16 GPU activations with C a multiple of 64."""
     if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4):
         return False
     C = x.shape[1]
-    return C % 8 == 0 and C <= 2048 and (C // 8) & (C // 8 - 1) == 0 and x.is_contiguous(memory_format=torch.channels_last)
+    return C % 64 == 0 and C <= 8192 and x.is_contiguous(memory_format=torch.channels_last)
 
 
 def _bn_partials(M: int, C: int) -> int:
-    """Same geometry as bn_geom() in csrc/bn.hip (checked against cp2_bn_num_partials in tests/test_cabi.py)."""
-    rp = 256 // (C // 8)
-    rpb = max(rp, -(-(-(-M // 512)) // rp) * rp)
+    """Same geometry as bn_geom_stats() in csrc/bn.hip (checked against cp2_bn_num_partials in tests/test_cabi.py)."""
+    cg = C // 8
+    cgs = 16 if cg % 16 == 0 else 8
+    ns, rp = cg // cgs, 256 // cgs
+    gr = max(1, min(1024 // ns, M // (4 * rp), 256))
+    rpb = -(-(-(-M // gr)) // rp) * rp
     return -(-M // rpb)
 
 
@@ -432,13 +435,14 @@ def bn_fwd(x, residual, weight, bias, running_mean, running_var, momentum: float
     N, C, H, W = x.shape
     M = N * H * W
     G = _bn_partials(M, C)
+    stream = _stream()
     y = torch.empty_like(x)                               # channels-last like x
     ws = torch.empty((2 * G + 4, C), dtype=torch.float32, device=x.device)   # partials | scale, shift | mean, invstd
     base, row = ws.data_ptr(), 4 * C
     rc = lib.cp2_bn_fwd(x.data_ptr(), residual.data_ptr() if residual is not None else None,
                         weight.data_ptr(), bias.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(),
                         momentum, eps, int(relu), y.data_ptr(), base + (2 * G + 2) * row, base + (2 * G + 3) * row,
-                        base, base + 2 * G * row, M, C, _stream())
+                        base, base + 2 * G * row, M, C, stream)
     if rc:
         _lib.check(rc, "cp2_bn_fwd")
     return y, ws[2 * G + 2:]
@@ -449,6 +453,7 @@ def bn_bwd(x, dy, y, weight, stats, relu: bool, want_dres: bool):
     N, C, H, W = x.shape
     M = N * H * W
     G = _bn_partials(M, C)
+    stream = _stream()
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if (want_dres and relu) else None
     ws = torch.empty((2 * G + 5, C), dtype=torch.float32, device=x.device)   # partials | coef[3] | dgamma, dbeta
@@ -456,7 +461,7 @@ def bn_bwd(x, dy, y, weight, stats, relu: bool, want_dres: bool):
     sp = stats.data_ptr()
     rc = lib.cp2_bn_bwd(x.data_ptr(), dy.data_ptr(), y.data_ptr() if relu else None, weight.data_ptr(), sp, sp + row,
                         int(relu), dx.data_ptr(), dres.data_ptr() if dres is not None else None,
-                        base + (2 * G + 3) * row, base + (2 * G + 4) * row, base, base + 2 * G * row, M, C, _stream())
+                        base + (2 * G + 3) * row, base + (2 * G + 4) * row, base, base + 2 * G * row, M, C, stream)
     if rc:
         _lib.check(rc, "cp2_bn_bwd")
     if want_dres and not relu:

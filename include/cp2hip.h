@@ -175,12 +175,13 @@ int cp2_masked_quantiles(const float* x, int64_t stride_row, int64_t stride_elem
 /* ---- encoder fast path (not a reference call site): fused training-mode BatchNorm (+ residual) (+ ReLU) --------
  * for channels-last bf16 activations, replacing MIOpen's 3 BN kernels + ATen add + clamp (forward) and 3 BN kernels +
  * threshold_backward (backward) of mmseg's ResNet blocks (mmseg_/models/backbones/resnet.py:267-304).
- * x, residual, y, dy, dx, dres: [M = N*H*W, C] bf16 (device pointers, 16-byte aligned); C in {64,...,2048} (8 * 2^k).
+ * x, residual, y, dy, dx, dres: [M = N*H*W, C] bf16 (device pointers, 16-byte aligned); C % 64 == 0, C <= 8192.
  * forward : y = relu?(x*scale + shift + residual?), batch statistics in fp32; running_mean / running_var (may be NULL)
  *           are updated as torch.nn.BatchNorm2d does (momentum, unbiased variance); save_mean, save_invstd: [C] out.
- *           Workspaces: part float[cp2_bn_num_partials(M,C), 2, C], scale_shift float[2, C].
+ *           Workspaces: part float[cp2_bn_num_partials(M,C), 2, C] (16-byte aligned), scale_shift float[2, C].
  * backward: g = dy * (y > 0) when relu (y = forward output, else NULL);  dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat));
- *           dres (NULL or [M,C]) = g;  dgamma, dbeta: [C] fp32 (may be NULL).  Workspaces: part as above, coef float[3, C]. */
+ *           dres (NULL or [M,C]) = g;  dgamma, dbeta: [C] fp32 (may be NULL).  Workspaces: part as above,
+ *           coef float[3, C]. */
 int cp2_bn_num_partials(int M, int C);
 int cp2_bn_fwd(const void* x, const void* residual, const float* weight, const float* bias, float* running_mean,
                float* running_var, float momentum, float eps, int relu, void* y, float* save_mean, float* save_invstd,

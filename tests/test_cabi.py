@@ -37,6 +37,8 @@ def test_ema_scalars_follow_python_double_arithmetic():
 def test_bn_partial_count_matches_library():
     lib = _lib.load()
     for M in (1, 3, 6272, 25088, 100352, 401408, 777):
-        for C in (64, 128, 256, 512, 1024, 2048):
-            assert ops._bn_partials(M, C) == lib.cp2_bn_num_partials(M, C), (M, C)
-    assert lib.cp2_bn_num_partials(100, 96) == -3 and lib.cp2_bn_num_partials(100, 4096) == -3
+        for C in (64, 128, 192, 256, 512, 1024, 2048, 4096):
+            g = lib.cp2_bn_num_partials(M, C)
+            assert 1 <= g <= 256 and ops._bn_partials(M, C) == g, (M, C)
+    assert lib.cp2_bn_num_partials(100, 96) == -3 and lib.cp2_bn_num_partials(100, 8256) == -3
+    assert lib.cp2_bn_num_partials(0, 64) == -2

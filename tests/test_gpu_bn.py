@@ -19,7 +19,8 @@ def close(got, want, rel, what):
     assert err <= lim, f"{what}: {err:.3e} > {lim:.3e}"
 
 
-@pytest.mark.parametrize("N,C,H,W", [(32, 64, 56, 56), (5, 256, 7, 9), (32, 2048, 14, 14), (3, 128, 1, 1), (2, 512, 13, 5)])
+@pytest.mark.parametrize("N,C,H,W", [(32, 64, 56, 56), (5, 256, 7, 9), (32, 2048, 14, 14), (3, 128, 1, 1), (2, 512, 13, 5),
+                                     (4, 192, 9, 9), (32, 1024, 14, 14), (8, 256, 56, 56)])
 @pytest.mark.parametrize("relu,use_res", [(True, False), (True, True), (False, False), (False, True)])
 def test_fused_bn_matches_fp32_batchnorm(N, C, H, W, relu, use_res):
     torch.manual_seed(C + H)
@@ -59,6 +60,25 @@ def test_fused_bn_matches_fp32_batchnorm(N, C, H, W, relu, use_res):
         assert (e2 > 1.6e-2 * rr.grad.abs().max().item()).float().mean().item() < 2e-3, "dres"
     sd = fused.state_dict()
     assert set(sd) == set(ref.state_dict()) and int(sd["num_batches_tracked"]) == 1
+
+
+def test_fused_bn_is_run_to_run_identical():
+    """Partial sums are combined in a fixed order (no atomics): repeated launches are bit-identical."""
+    torch.manual_seed(1)
+    outs = []
+    for C, H in ((64, 56), (2048, 14), (256, 28)):
+        x = torch.randn(16, C, H, H, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        up = torch.randn_like(x)
+        for rep in range(3):
+            bn = FusedBatchNorm2d(C).to(DEV).train()
+            xf = x.clone().requires_grad_(True)
+            y = bn(xf, relu=True)
+            y.backward(up)
+            cur = (y.detach().clone(), xf.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(), bn.running_var.clone())
+            if rep:
+                for a, b in zip(outs, cur):
+                    assert torch.equal(a, b)
+            outs = cur
 
 
 def test_fallback_paths_match_stock_batchnorm():

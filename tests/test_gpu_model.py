@@ -170,3 +170,31 @@ def test_key_weight_shadow_is_exact_and_used():
         for m, w in saved.items():
             m.shadow_weight = w
     assert torch.equal(y1, y2)
+
+
+def test_key_forward_graph_equals_eager_key_forward():
+    """The key encoder forward replayed from a hipGraph (engine.ForwardGraph: 3 eager calls, capture, replays) gives
+    the same features and leaves the same BN running statistics / batch counters as the eager forward."""
+    models = []
+    for use_graph in (True, False):
+        m = small_model(amp_dtype=torch.bfloat16, channels_last=True)
+        m.encoder_q.to(memory_format=torch.channels_last)
+        m.encoder_k.to(memory_format=torch.channels_last)
+        m.key_forward_graph = use_graph
+        m.flatten_parameters()
+        m._momentum_update_key_encoder()                     # fills the bf16 key-weight shadow
+        models.append(m)
+    for i in range(7):
+        img = torch.randn(8, 3, 64, 64, device=DEV, generator=torch.Generator(DEV).manual_seed(i))
+        with torch.no_grad():
+            ka = models[0]._encode_key(img).clone()
+            kb = models[1]._encode_key(img).clone()
+        assert torch.equal(ka, kb), i
+    g = models[0]._key_graph
+    assert g is not None and any(e["graph"] is not None for e in g.entries.values())
+    assert models[1]._key_graph is None
+    sa, sb = models[0].state_dict(), models[1].state_dict()
+    for name in sa:
+        if name.startswith("encoder_k."):
+            assert torch.equal(sa[name], sb[name]), name
+    assert int(sa["encoder_k.backbone.bn1.num_batches_tracked"]) == 7
