@@ -46,6 +46,8 @@ def parse():
                         "gradients of four 1x1 convolutions come back as garbage under graph REPLAY (DESIGN.md section 5); "
                         "eager mode is within 2 %% of the graph anyway (the GPU is saturated)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--flat-sgd", default="on", choices=["on", "off"],
+                   help="optimizer step as one HIP launch on the flat parameter buffer (off: torch.optim.SGD) (A/B)")
     p.add_argument("--fused-bn", default="on", choices=["on", "off"], help="encoder fast path: fused BN(+add)(+ReLU) kernels (A/B)")
     p.add_argument("--overlap", default="auto", choices=["auto", "on", "off"],
                    help="key branch (EMA, shuffle all-gathers, key encoder) on a side HIP stream; auto = when N > 1")
@@ -111,7 +113,8 @@ def main():
 
     class A:  # optimizer settings of reference main.py defaults
         lr, momentum, weight_decay, optim = 0.03, 0.9, 1e-4, "sgd"
-    opt = make_optimizer(list(model.parameters()), A, dev, capturable=use_graph)
+    opt = make_optimizer(list(model.parameters()), A, dev, capturable=use_graph,
+                         model=model if args.flat_sgd == "on" else None)
     b, hw = args.batch_per_gpu, args.img
     batches = [synthetic.make_batch(b, hw, hw, dev, seed=rank * 9973 + i) for i in range(4)]
     flops_img = count_flops_per_image(model, batches[0])

@@ -243,6 +243,8 @@ class MODEL(nn.Module):
         self.log_quartiles = True        # per-step quartile statistics of the reference (builder.py:1298,1399-1406), sort-free
         self.key_weight_shadow = amp_dtype == torch.bfloat16   # EMA also emits bf16 key weights for the key encoder's convs
         self._flat_k_bf16 = None
+        self._flat_q_bf16 = None         # bf16 image of the query weights, written by optim.FlatSGD (enable_query_shadow)
+        self._q_shadow_version = None
         self.ema_in_forward = True       # False: the caller runs _momentum_update_key_encoder() itself before forward
         self.overlap_key_branch = None   # key branch on a side stream: None = only when world size > 1 (no gain at N=1)
         self._side_stream = None
@@ -289,6 +291,45 @@ class MODEL(nn.Module):
                     mod.shadow_weight = torch.as_strided(self._flat_k_bf16, mod.weight.shape, mod.weight.stride(),
                                                          by_param[id(mod.weight)])
         self._flat_q, self._flat_k, self._flat_offsets = flat_q, flat_k, offs
+        if self._flat_q_bf16 is not None:                   # re-homed: the old image belongs to the old buffer
+            self._flat_q_bf16 = None
+            self.enable_query_shadow()
+
+    # ------------------------------------------------------------------ bf16 image of the query weights
+    def enable_query_shadow(self):
+        """Give the query encoder's convolutions a bf16 image of their weights (one flat buffer, same offsets as the
+        fp32 parameters) so bf16 autocast launches no cast kernel per weight tensor.  optim.FlatSGD writes the image
+        in its update kernel; any other in-place change of a parameter is noticed through the tensors' version
+        counters at the next forward and the image is rebuilt (_refresh_query_shadow)."""
+        if self.amp_dtype != torch.bfloat16 or self._flat_q is None or self._flat_q_bf16 is not None:
+            return
+        from .encoder import Conv2d
+        self._flat_q_bf16 = torch.empty(self._flat_q.numel(), dtype=torch.bfloat16, device=self._flat_q.device)
+        pq = list(self.encoder_q.parameters())
+        by_param = {id(p): o for p, o in zip(pq, self._flat_offsets)}
+        for mod in self.encoder_q.modules():
+            if isinstance(mod, Conv2d) and id(mod.weight) in by_param:
+                mod.shadow_weight = torch.as_strided(self._flat_q_bf16, mod.weight.shape, mod.weight.stride(),
+                                                     by_param[id(mod.weight)])
+        self._q_shadow_params = pq
+        self._q_shadow_version = None
+        self._refresh_query_shadow()
+
+    def _query_version(self):
+        return sum(p._version for p in self._q_shadow_params)
+
+    def _query_shadow_written(self):
+        """Called by the optimizer kernel's host side: image and parameters were written together."""
+        if self._flat_q_bf16 is not None:
+            self._q_shadow_version = self._query_version()
+
+    def _refresh_query_shadow(self):
+        if self._flat_q_bf16 is None:
+            return
+        v = self._query_version()
+        if v != self._q_shadow_version:
+            ops.bf16_image(self._flat_q, self._flat_q_bf16)
+            self._q_shadow_version = v
 
     @torch.no_grad()
     def _momentum_update_key_encoder(self):
@@ -402,6 +443,7 @@ class MODEL(nn.Module):
         # the query encoder, so it runs on a side HIP stream: its RCCL all-gathers and small kernels overlap with
         # the query forward on the main stream (reference order builder.py:1260-1277 is serial).
         self.flatten_parameters()        # on the main stream, before the fork: it re-homes the query parameters too
+        self._refresh_query_shadow()
         cur = torch.cuda.current_stream()
         overlap = cdist.world_size() > 1 if self.overlap_key_branch is None else self.overlap_key_branch
         side = self._key_stream() if overlap else cur

@@ -80,15 +80,31 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
         super()._save_to_state_dict(destination, prefix, keep_vars)
 
 
+class _ShadowWeightFn(torch.autograd.Function):
+    """bf16 image of an fp32 weight as seen by autograd: forward hands out the image (no cast kernel), backward
+    returns the gradient in fp32 to the master weight -- what autocast's own cast node does."""
+
+    @staticmethod
+    def forward(ctx, weight, shadow):
+        return shadow.view_as(shadow)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.float32), None
+
+
 class Conv2d(nn.Conv2d):
     """nn.Conv2d that uses `shadow_weight` -- a bf16 copy of `weight` kept current by someone else (the EMA kernel
-    writes it for the key encoder) -- when the input is bf16, so autocast launches no per-tensor cast kernel."""
+    writes it for the key encoder, the optimizer kernel for the query encoder) -- when the input is bf16, so autocast
+    launches no per-tensor cast kernel."""
 
     shadow_weight = None
 
     def forward(self, x):
         w = self.shadow_weight
         if w is not None and x.dtype == torch.bfloat16:
+            if self.weight.requires_grad and torch.is_grad_enabled():
+                w = _ShadowWeightFn.apply(self.weight, w)
             b = self.bias.to(torch.bfloat16) if self.bias is not None else None
             return self._conv_forward(x, w, b)
         return super().forward(x)

@@ -117,12 +117,16 @@ def get_args(argv=None):
     return args
 
 
-def make_optimizer(params, args, device, capturable: bool):
+def make_optimizer(params, args, device, capturable: bool, model=None):
     """SGD(momentum, wd) / AdamW as reference main.py:467-477.  For hipGraph capture the learning rate is
-    a device tensor and the update is torch's fused multi-tensor kernel, so the LR schedule needs no re-capture."""
+    a device tensor, so the LR schedule needs no re-capture.  With `model` (a builder.MODEL on the GPU) the SGD step is
+    cp2_amd.optim.FlatSGD: the same update as torch.optim.SGD, bit for bit, in one HIP launch on the flat buffer."""
     lr = torch.tensor(float(args.lr), device=device) if capturable else args.lr
     if args.optim == "adamw":
         return torch.optim.AdamW(params, lr, weight_decay=0.01, fused=capturable or None, capturable=capturable)
+    if args.optim == "sgd" and model is not None and torch.device(device).type == "cuda":
+        from .optim import FlatSGD
+        return FlatSGD(model, lr, momentum=args.momentum, weight_decay=args.weight_decay)
     if args.optim == "sgd":
         return torch.optim.SGD(params, lr, momentum=args.momentum, weight_decay=args.weight_decay,
                                fused=True if capturable else None)
@@ -188,7 +192,7 @@ def main_worker(rank, args):
         # no unused-parameter search is needed either.
         wrapped = DistributedDataParallel(model, device_ids=[local], output_device=local, broadcast_buffers=False,
                                           gradient_as_bucket_view=True)
-    optimizer = make_optimizer([p for p in model.parameters()], args, device, capturable=use_graph)
+    optimizer = make_optimizer([p for p in model.parameters()], args, device, capturable=use_graph, model=model)
     if args.resume and os.path.isfile(args.resume):
         ck = torch.load(args.resume, map_location=device)
         args.start_epoch = ck["epoch"]

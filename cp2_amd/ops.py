@@ -150,6 +150,55 @@ def ema_flat_timed(k: torch.Tensor, q: torch.Tensor, m: float, events) -> None:
     _lib.check(rc, "cp2_ema_flat_timed")
 
 
+def bf16_image(src: torch.Tensor, dst: torch.Tensor) -> None:
+    """dst = bf16(src) for flat buffers of equal length (a multiple of 4)."""
+    lib = _lib.load()
+    if src.numel() != dst.numel():
+        raise ValueError("bf16_image: buffers differ in size")
+    rc = lib.cp2_bf16_image(_dev(src, "src", torch.float32), _dev(dst, "dst", torch.bfloat16), src.numel(), _stream())
+    _lib.check(rc, "cp2_bf16_image")
+
+
+SGD_BLOCK_FLOATS = 512      # floats per workgroup of sgd_flat_kernel (csrc/sgd.hip)
+
+
+class SgdFlatPlan:
+    """Static tables of cp2_sgd_flat for a flat parameter buffer: `offsets[i]`, `numels[i]` = slot start and element
+    count of tensor i (slots are 256-byte aligned, see MODEL.flatten_parameters)."""
+
+    def __init__(self, offsets, numels, device):
+        import ctypes
+
+        import numpy as np
+        rows, first = [], [0]
+        for t, (off, n) in enumerate(zip(offsets, numels)):
+            if off % 4:
+                raise ValueError("SgdFlatPlan: slots must start on 16-byte boundaries")
+            for g in range(0, n, SGD_BLOCK_FLOATS):
+                rows.append((t, off + g, g, min(SGD_BLOCK_FLOATS, n - g)))
+            first.append(len(rows))
+        self.ntensors = len(numels)
+        self.blk_tab = torch.from_numpy(np.asarray(rows, dtype=np.int32).reshape(-1, 4)).to(device)
+        self.first = (ctypes.c_int32 * len(first))(*first)
+        self.grads = (ctypes.c_void_p * self.ntensors)()
+
+
+def sgd_flat(plan: SgdFlatPlan, p: torch.Tensor, buf: torch.Tensor, p_bf16: Optional[torch.Tensor], lr, momentum: float,
+             weight_decay: float) -> None:
+    """One SGD(momentum, weight decay) step on the flat buffer; plan.grads[i] must hold the device pointer of tensor
+    i's fp32 gradient (element order of its slot) or None.  `lr`: float, or a one-element fp32 device tensor."""
+    import numpy as np
+    lib = _lib.load()
+    lr_dev = None
+    if isinstance(lr, torch.Tensor):
+        lr_dev, lr = _dev(lr, "lr", torch.float32), 0.0
+    rc = lib.cp2_sgd_flat(_dev(p, "p", torch.float32), _dev(buf, "momentum_buf", torch.float32),
+                          _opt(p_bf16, "p_bf16", torch.bfloat16), plan.grads, plan.ntensors, plan.blk_tab.data_ptr(),
+                          plan.first, float(np.float32(lr)), lr_dev, float(np.float32(momentum)),
+                          float(np.float32(weight_decay)), _stream())
+    _lib.check(rc, "cp2_sgd_flat")
+
+
 class EmaMultiPlan:
     """Device tables for cp2_ema_multi over two parameter lists (built once, reused every step)."""
 

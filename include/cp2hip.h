@@ -172,6 +172,23 @@ int cp2_masked_quantiles(const float* x, int64_t stride_row, int64_t stride_elem
                          const float* mask_a, const float* mask_b, int P, int want, const float* q, int NQ,
                          float* out, void* stream);
 
+/* ---- optimizer step of the query encoder on the flat parameter buffer ---------------- main.py:467-477, :640-642
+ * torch.optim.SGD(momentum, weight_decay) (dampening 0, no Nesterov), bit-identical to torch's default multi-tensor
+ * implementation on the same GPU:  g' = g + wd*p;  buf = buf*momentum + g';  p = p - lr*buf.
+ * p, momentum_buf: flat fp32 device buffers (16-byte aligned) holding every parameter in a slot; p_bf16: NULL or a
+ * bf16 buffer with the same element offsets that receives the new weights (the query encoder's convolutions read it
+ * under bf16 autocast).  grads: HOST array of ntensors DEVICE pointers (fp32, element order of the parameter's slot;
+ * NULL = no gradient, parameter untouched).  blk_tab: DEVICE int32[nblocks][4] = {tensor, flat offset, gradient
+ * offset, valid floats (<= 512)} -- workgroup b updates floats [flat offset, +valid) of tensor blk_tab[b][0];
+ * tensor_first_block: HOST int32[ntensors+1], the blocks of tensor t are [first[t], first[t+1]).
+ * lr_dev: NULL, or a device float that overrides lr (graph capture).  momentum_buf must start as zeros. */
+#define CP2_SGD_MAX_TENSORS 384
+int cp2_sgd_flat(float* p, float* momentum_buf, void* p_bf16, const void* const* grads, int ntensors,
+                 const int32_t* blk_tab, const int32_t* tensor_first_block, float lr, const float* lr_dev,
+                 float momentum, float weight_decay, void* stream);
+/* dst[i] = bf16(src[i]) (round to nearest even) for a flat buffer, n % 4 == 0: rebuilds the bf16 weight image. */
+int cp2_bf16_image(const float* src, void* dst, int64_t n, void* stream);
+
 /* ---- encoder fast path (not a reference call site): fused training-mode BatchNorm (+ residual) (+ ReLU) --------
  * for channels-last bf16 activations, replacing MIOpen's 3 BN kernels + ATen add + clamp (forward) and 3 BN kernels +
  * threshold_backward (backward) of mmseg's ResNet blocks (mmseg_/models/backbones/resnet.py:267-304).

@@ -174,7 +174,10 @@ def test_key_weight_shadow_is_exact_and_used():
 
 def test_key_forward_graph_equals_eager_key_forward():
     """The key encoder forward replayed from a hipGraph (engine.ForwardGraph: 3 eager calls, capture, replays) gives
-    the same features and leaves the same BN running statistics / batch counters as the eager forward."""
+    the same features and leaves the same BN running statistics / batch counters as the eager forward.
+    Tolerance: MIOpen's bf16 forward solvers may use split-K atomics (not run-to-run reproducible), so features are
+    compared to bf16 precision (2e-2 of the largest value) and running statistics to 1e-2; a replay that read a stale
+    input or stale weights would be off by O(1): every call uses a different image."""
     models = []
     for use_graph in (True, False):
         m = small_model(amp_dtype=torch.bfloat16, channels_last=True)
@@ -189,12 +192,13 @@ def test_key_forward_graph_equals_eager_key_forward():
         with torch.no_grad():
             ka = models[0]._encode_key(img).clone()
             kb = models[1]._encode_key(img).clone()
-        assert torch.equal(ka, kb), i
+        assert (ka.float() - kb.float()).abs().max().item() <= 2e-2 * kb.float().abs().max().item(), i
     g = models[0]._key_graph
     assert g is not None and any(e["graph"] is not None for e in g.entries.values())
     assert models[1]._key_graph is None
     sa, sb = models[0].state_dict(), models[1].state_dict()
     for name in sa:
         if name.startswith("encoder_k."):
-            assert torch.equal(sa[name], sb[name]), name
+            a, b = sa[name].float(), sb[name].float()
+            assert (a - b).abs().max().item() <= 1e-2 * b.abs().max().item() + 1e-6, name
     assert int(sa["encoder_k.backbone.bn1.num_batches_tracked"]) == 7

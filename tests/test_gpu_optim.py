@@ -1,0 +1,120 @@
+"""GPU: optim.FlatSGD (cp2_sgd_flat, csrc/sgd.hip) against torch.optim.SGD -- the optimizer the reference builds
+(main.py:467-477) -- on the same model, same gradients: parameters and momentum buffers must be bit-identical after
+every step, the bf16 image of the query weights must equal weight.to(bfloat16), and the optimizer state dict must
+round-trip in torch's layout."""
+import copy
+import os
+
+import pytest
+import torch
+
+from cp2_amd import builder, ops
+from cp2_amd.config import Config
+from cp2_amd.optim import FlatSGD
+from cp2_amd.pretrain_types import PretrainType
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def small_model(**kw):
+    torch.manual_seed(0)
+    cfg = Config.fromfile(os.path.join(ROOT, "configs", "config_pretrain_r18.py"))
+    m = builder.MODEL(cfg, rank=0, K=256, pretrain_from_scratch=True, pretrain_type=PretrainType.CP2, device=DEV, **kw)
+    return m.to(DEV).train()
+
+
+def fake_grads(params, seed):
+    g = torch.Generator(DEV).manual_seed(seed)
+    out = []
+    for i, p in enumerate(params):
+        if not p.requires_grad or i % 11 == 7:            # some parameters get no gradient in a step
+            out.append(None)
+            continue
+        t = torch.randn(p.shape, device=DEV, generator=g) * 0.1
+        if p.dim() == 4 and i % 3 == 0:                   # a gradient whose layout differs from the parameter's
+            t = t.contiguous(memory_format=torch.channels_last if p.is_contiguous() else torch.contiguous_format)
+        out.append(t)
+    return out
+
+
+@pytest.mark.parametrize("momentum,wd", [(0.9, 1e-4), (0.0, 1e-4), (0.9, 0.0)])
+def test_flat_sgd_is_bit_identical_to_torch_sgd(momentum, wd):
+    ma = small_model(amp_dtype=torch.bfloat16, channels_last=True)
+    ma.encoder_q.to(memory_format=torch.channels_last)
+    mb = copy.deepcopy(ma)
+    flat = FlatSGD(ma, 0.03, momentum=momentum, weight_decay=wd)
+    ref = torch.optim.SGD([p for p in mb.parameters() if p.requires_grad], 0.03, momentum=momentum, weight_decay=wd)
+    pa, pb = list(ma.encoder_q.parameters()), list(mb.encoder_q.parameters())
+    for step in range(4):
+        for p, q, g in zip(pa, pb, fake_grads(pa, step)):
+            p.grad = None if g is None else g.clone()
+            q.grad = None if g is None else g.clone()
+        if step == 2:
+            for grp in flat.param_groups + ref.param_groups:
+                grp["lr"] = 0.0123                          # the schedule of main.py:693-698 edits param_groups
+        flat.step()
+        ref.step()
+        for (n, p), q in zip(ma.encoder_q.named_parameters(), pb):
+            assert torch.equal(p, q), (step, n)
+        for p, q in zip(pa, pb):
+            sa, sb = flat.state.get(p, {}), ref.state.get(q, {})
+            assert ("momentum_buffer" in sa) == ("momentum_buffer" in sb and sb["momentum_buffer"] is not None)
+            if "momentum_buffer" in sa:
+                assert torch.equal(sa["momentum_buffer"], sb["momentum_buffer"])
+    # the bf16 image the query convolutions read is exactly weight.to(bfloat16)
+    from cp2_amd.encoder import Conv2d
+    seen = 0
+    for mod in ma.encoder_q.modules():
+        if isinstance(mod, Conv2d):
+            assert mod.shadow_weight is not None and torch.equal(mod.shadow_weight, mod.weight.to(torch.bfloat16))
+            seen += 1
+    assert seen >= 20
+    # optimizer state dict in torch's layout, loadable by torch.optim.SGD and back
+    sd = flat.state_dict()
+    assert sd["param_groups"][0]["lr"] == 0.0123 and len(sd["param_groups"][0]["params"]) == len(ref.state_dict()["param_groups"][0]["params"])
+    ref2 = torch.optim.SGD([p for p in mb.parameters() if p.requires_grad], 0.03, momentum=momentum, weight_decay=wd)
+    ref2.load_state_dict(sd)
+    flat.load_state_dict(ref.state_dict())
+    if momentum:
+        k = next(iter(sd["state"]))
+        assert torch.equal(sd["state"][k]["momentum_buffer"], ref.state_dict()["state"][k]["momentum_buffer"])
+
+
+def test_query_shadow_follows_foreign_parameter_changes():
+    """Any in-place change of a parameter that did not come from FlatSGD (load_state_dict, manual init) is noticed
+    at the next forward and the bf16 image is rebuilt."""
+    m = small_model(amp_dtype=torch.bfloat16, channels_last=True)
+    FlatSGD(m, 0.03, momentum=0.9, weight_decay=1e-4)
+    conv = m.encoder_q.backbone.layer2[0].conv1
+    assert torch.equal(conv.shadow_weight, conv.weight.to(torch.bfloat16))
+    with torch.no_grad():
+        conv.weight.mul_(1.5)
+    assert not torch.equal(conv.shadow_weight, conv.weight.to(torch.bfloat16))
+    m._refresh_query_shadow()
+    assert torch.equal(conv.shadow_weight, conv.weight.to(torch.bfloat16))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd["encoder_q.backbone.layer2.0.conv1.weight"].add_(0.25)
+    m.load_state_dict(sd)
+    m._refresh_query_shadow()
+    assert torch.equal(conv.shadow_weight, conv.weight.to(torch.bfloat16))
+
+
+def test_training_step_with_flat_sgd_matches_torch_sgd_step():
+    """Whole eager steps: model + FlatSGD vs model + torch.optim.SGD from the same state and batches."""
+    from cp2_amd import synthetic
+    from cp2_amd.engine import TrainStep
+    losses = []
+    for use_flat in (True, False):
+        m = small_model(amp_dtype=torch.bfloat16, channels_last=True)
+        m.encoder_q.to(memory_format=torch.channels_last)
+        m.encoder_k.to(memory_format=torch.channels_last)
+        opt = FlatSGD(m, 0.03, momentum=0.9, weight_decay=1e-4) if use_flat else \
+            torch.optim.SGD([p for p in m.parameters() if p.requires_grad], 0.03, momentum=0.9, weight_decay=1e-4)
+        run = TrainStep(m, opt, use_graph=False)
+        torch.manual_seed(7)
+        losses.append([float(run(synthetic.make_batch(8, 64, 64, DEV, seed=i))) for i in range(4)])
+    # same maths; MIOpen's bf16 split-K kernels (atomics, forward and weight gradient) are not run-to-run reproducible
+    assert abs(losses[0][0] - losses[1][0]) <= 1e-3 and abs(losses[0][1] - losses[1][1]) <= 3e-3, losses
+    assert all(abs(a - b) < 5e-2 for a, b in zip(*losses)), losses
