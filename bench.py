@@ -46,6 +46,8 @@ def parse():
                         "gradients of four 1x1 convolutions come back as garbage under graph REPLAY (DESIGN.md section 5); "
                         "eager mode is within 2 %% of the graph anyway (the GPU is saturated)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--gemm-1x1", default="on", choices=["on", "off"],
+                   help="1x1 stride-1 convolutions: hipBLASLt GEMM for forward / data gradient where faster (A/B)")
     p.add_argument("--flat-sgd", default="on", choices=["on", "off"],
                    help="optimizer step as one HIP launch on the flat parameter buffer (off: torch.optim.SGD) (A/B)")
     p.add_argument("--fused-bn", default="on", choices=["on", "off"], help="encoder fast path: fused BN(+add)(+ReLU) kernels (A/B)")
@@ -91,6 +93,8 @@ def main():
     from cp2_amd import builder, ops, synthetic
     from cp2_amd.encoder import FusedBatchNorm2d
     FusedBatchNorm2d.fused = args.fused_bn == "on"
+    from cp2_amd.encoder import Conv2d
+    Conv2d.gemm_1x1 = args.gemm_1x1 == "on"
     from cp2_amd.config import Config
     from cp2_amd.engine import TrainStep
     from cp2_amd.main import make_optimizer

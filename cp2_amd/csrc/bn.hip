@@ -70,7 +70,9 @@ __device__ __forceinline__ void bn_bwd_channel(const BnFin& f, int c, int M, int
 // statistics: workgroup (chunk, slice) -> two per-channel sums over rows [chunk*rpb, ...) of the slice's 64 / 128
 // channels, part[chunk][2][C].   MODE 0: (x, x^2)   MODE 1: (g, g*xhat), g = dy * (y > 0)
 // (Letting the last-arriving workgroup of a slice run the epilogue in the same launch was measured and rejected: the
-// agent-scope release it needs is a buffer_wbl2 per workgroup, 46 us per launch instead of 7.)
+// agent-scope release it needs is a buffer_wbl2 per workgroup, 46 us per launch instead of 7.  So was letting the
+// apply workgroups of small layers add the partials themselves: the load -> LDS -> math -> LDS prologue costs what the
+// finalize launch costs, 5.6 -> 9.4 us per forward apply, and the 32-chunk cap it needs slows the statistics kernels.)
 // ---------------------------------------------------------------------------------------------------------------
 template <int MODE, bool RELU>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const u16x8* __restrict__ x, const u16x8* __restrict__ dy,

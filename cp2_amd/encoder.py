@@ -93,21 +93,85 @@ class _ShadowWeightFn(torch.autograd.Function):
         return g.to(torch.float32), None
 
 
+class _Conv1x1Fn(torch.autograd.Function):
+    """1x1 stride-1 convolution on channels-last bf16 activations = a plain GEMM over the [N*H*W, C] view.
+    MIOpen's implicit-GEMM solvers lose to hipBLASLt on the data gradient of almost every such layer of the ResNet
+    (MI355X, graph-replayed launches: 393 -> 263 us summed over the distinct ResNet-50 shapes) and on the forward of
+    the wide low-resolution ones, while hipBLASLt's [Co, M] x [M, Ci] weight gradient is 4-15x slower at large M:
+    forward and data gradient pick the GEMM per shape (`mm_fwd`, `mm_dgrad`), the weight gradient stays with MIOpen.
+    `weight` is the fp32 master (receives the fp32 gradient, as autocast's cast node would deliver it), `shadow` its
+    bf16 image."""
+
+    @staticmethod
+    def forward(ctx, x, weight, shadow, bias, mm_fwd, mm_dgrad):
+        N, C, H, W = x.shape
+        co = shadow.shape[0]
+        b16 = bias.to(torch.bfloat16) if bias is not None else None
+        if mm_fwd:
+            x2, w2 = x.permute(0, 2, 3, 1).reshape(-1, C), shadow.reshape(co, C)
+            y2 = torch.mm(x2, w2.t()) if b16 is None else torch.addmm(b16, x2, w2.t())
+            y = y2.view(N, H, W, co).permute(0, 3, 1, 2)
+        else:
+            y = F.conv2d(x, shadow, b16)
+        ctx.save_for_backward(x, shadow)
+        ctx.mm_dgrad, ctx.has_bias = mm_dgrad, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        N, C, H, W = x.shape
+        co = w.shape[0]
+        if dy.dtype != torch.bfloat16 or not dy.is_contiguous(memory_format=torch.channels_last):
+            dy = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        need_dx, need_dw, need_db = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[3]
+        dx = None
+        if need_dx and ctx.mm_dgrad:
+            dx = torch.mm(dy.permute(0, 2, 3, 1).reshape(-1, co), w.reshape(co, C)).view(N, H, W, C).permute(0, 3, 1, 2)
+        rest = torch.ops.aten.convolution_backward(dy, x, w, [co] if need_db else None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                   [need_dx and dx is None, need_dw, bool(need_db)])
+        if need_dx and dx is None:
+            dx = rest[0]
+        dw = rest[1].to(torch.float32) if need_dw else None
+        db = rest[2].to(torch.float32) if need_db else None
+        return dx, dw, None, db, None, None
+
+
 class Conv2d(nn.Conv2d):
     """nn.Conv2d that uses `shadow_weight` -- a bf16 copy of `weight` kept current by someone else (the EMA kernel
     writes it for the key encoder, the optimizer kernel for the query encoder) -- when the input is bf16, so autocast
-    launches no per-tensor cast kernel."""
+    launches no per-tensor cast kernel; 1x1 stride-1 layers go through _Conv1x1Fn (GEMM where it is faster)."""
 
     shadow_weight = None
+    gemm_1x1 = True          # class-wide switch (A/B)
 
     def forward(self, x):
         w = self.shadow_weight
         if w is not None and x.dtype == torch.bfloat16:
+            if (Conv2d.gemm_1x1 and self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0)
+                    and self.groups == 1 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
+                m, ci, co = x.shape[0] * x.shape[2] * x.shape[3], self.in_channels, self.out_channels
+                mm_fwd = m <= 32768 and ci * co >= 131072
+                if not (torch.is_grad_enabled() and (self.weight.requires_grad or x.requires_grad)):
+                    if mm_fwd:                      # gradient-free forward (key encoder): no autograd node needed
+                        return _Conv1x1Fn.forward(_NoCtx, x, None, w, self.bias, True, False)
+                elif torch.cuda.is_current_stream_capturing():
+                    # with autograd the Python-side Function costs ~0.1 ms of host time per layer and step: worth it
+                    # only when the step is being captured into a hipGraph (host time is then paid once)
+                    return _Conv1x1Fn.apply(x, self.weight, w, self.bias, mm_fwd, ci >= 128)
             if self.weight.requires_grad and torch.is_grad_enabled():
                 w = _ShadowWeightFn.apply(self.weight, w)
             b = self.bias.to(torch.bfloat16) if self.bias is not None else None
             return self._conv_forward(x, w, b)
         return super().forward(x)
+
+
+class _NoCtx:
+    """Stand-in for the autograd context when _Conv1x1Fn.forward is used as a plain function."""
+
+    @staticmethod
+    def save_for_backward(*a):
+        pass
 
 
 class ConvBNAct(nn.Module):

@@ -1,0 +1,68 @@
+"""GPU: encoder plumbing around the hot path -- the 1x1 convolution routed through hipBLASLt (_Conv1x1Fn) against
+F.conv2d on the same bf16 operands (tolerance: bf16 outputs, 2e-2 of the largest reference value; fp32 parameter
+gradients 2e-2 as both sides accumulate bf16 products in different orders)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from cp2_amd.encoder import Conv2d, _Conv1x1Fn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def close(got, want, rel, what):
+    err = (got.float() - want.float()).abs().max().item()
+    lim = rel * want.float().abs().max().item() + 1e-6
+    assert err <= lim, f"{what}: {err:.3e} > {lim:.3e}"
+
+
+@pytest.mark.parametrize("N,HW,ci,co", [(8, 14, 512, 2048), (8, 14, 1024, 256), (4, 28, 512, 128), (2, 56, 64, 256), (3, 7, 256, 128)])
+@pytest.mark.parametrize("bias", [False, True])
+@pytest.mark.parametrize("mm_fwd,mm_dgrad", [(True, True), (False, True), (True, False), (False, False)])
+def test_conv1x1_function_matches_conv2d(N, HW, ci, co, bias, mm_fwd, mm_dgrad):
+    torch.manual_seed(ci + co)
+    x = torch.randn(N, ci, HW, HW, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(co, ci, 1, 1, device=DEV) * ci ** -0.5).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(co, device=DEV) if bias else None
+    up = torch.randn(N, co, HW, HW, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    xa, wa = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ba = b.clone().requires_grad_(True) if bias else None
+    y = _Conv1x1Fn.apply(xa, wa, wa.detach().to(torch.bfloat16), ba, mm_fwd, mm_dgrad)
+    assert y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(up)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        yr = F.conv2d(xr, wr, br)
+    yr.backward(up)
+    close(y, yr, 2e-2, "y")
+    close(xa.grad, xr.grad, 2e-2, "dx")
+    assert wa.grad.dtype == torch.float32 and wa.grad.shape == w.shape
+    close(wa.grad, wr.grad, 2e-2, "dw")
+    if bias:
+        close(ba.grad, br.grad, 2e-2, "dbias")
+
+
+def test_conv2d_module_routes_1x1_and_keeps_other_layers():
+    torch.manual_seed(1)
+    conv = Conv2d(512, 1024, 1, bias=False).to(DEV).to(memory_format=torch.channels_last)
+    conv.shadow_weight = conv.weight.detach().to(torch.bfloat16)
+    x = torch.randn(8, 512, 14, 14, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = conv(x)                                    # eager + autograd: the MIOpen path (the Function costs host time)
+    assert type(y.grad_fn).__name__ != "_Conv1x1FnBackward"
+    y.float().square().mean().backward()
+    assert conv.weight.grad is not None and conv.weight.grad.dtype == torch.float32 and x.grad is not None
+    with torch.no_grad():                          # gradient-free forward: GEMM, same values to bf16 precision
+        yg = conv(x)
+        Conv2d.gemm_1x1 = False
+        try:
+            yc = conv(x)
+        finally:
+            Conv2d.gemm_1x1 = True
+    assert yg.is_contiguous(memory_format=torch.channels_last)
+    close(yg, yc, 2e-2, "no-grad forward")
+    c3 = Conv2d(64, 64, 3, padding=1, bias=False).to(DEV).to(memory_format=torch.channels_last)
+    c3.shadow_weight = c3.weight.detach().to(torch.bfloat16)
+    x3 = torch.randn(2, 64, 8, 8, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert type(c3(x3).grad_fn).__name__ != "_Conv1x1FnBackward"
