@@ -104,8 +104,10 @@ def main():
     torch.backends.cudnn.benchmark = True
     cfg = Config.fromfile(args.config)
     amp = torch.bfloat16 if args.amp == "bf16" else None
-    model = builder.MODEL(cfg, rank=rank, K=args.queue, pretrain_from_scratch=True, pretrain_type=PretrainType.CP2,
-                          device=dev, amp_dtype=amp, channels_last=True).to(dev)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):       # the constructor prints what the reference prints; stdout = the JSON line only
+        model = builder.MODEL(cfg, rank=rank, K=args.queue, pretrain_from_scratch=True, pretrain_type=PretrainType.CP2,
+                              device=dev, amp_dtype=amp, channels_last=True).to(dev)
     model.encoder_q.to(memory_format=torch.channels_last)
     model.encoder_k.to(memory_format=torch.channels_last)
     model.train()

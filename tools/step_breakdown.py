@@ -17,3 +17,19 @@ print(f"wall/step {wall:.2f} ms, kernel-busy/step {busy/1e6/nsteps:.2f} ms, laun
 top=sorted(agg.items(), key=lambda kv:-kv[1][0])
 for n,(d,c) in top[:int(sys.argv[3]) if len(sys.argv)>3 else 45]:
     print(f"{d/1e6/nsteps:8.3f} ms/step {c/nsteps:7.1f} calls  avg {d/c/1e3:8.1f} us  {n[:130]}")
+
+# category roll-up (ms per step)
+def cat(n):
+    if n.startswith(('bn_', 'void bn_')): return 'fused BN kernels (csrc/bn.hip)'
+    if any(k in n for k in ('ema_flat', 'sgd_flat', 'bf16_image')): return 'EMA + optimizer kernels (csrc/ema.hip, sgd.hip)'
+    if any(k in n for k in ('rowkey', 'dense_', 'masked_quantile', 'feat_', 'pool_', 'compose', 'strided_gather', 'gather_rows',
+                            'corr_iou', 'enqueue', 'keys_split', 'mean_kernel')): return 'loss-section kernels (csrc/*.hip)'
+    if any(k in n for k in ('igemm', 'ck::', '_ZN2ck', 'SubTensorOp', 'Cijk', 'miopen', 'MIOpen', 'naive_conv', 'gemm')): return 'MIOpen / CK / hipBLASLt (convolutions, GEMMs)'
+    if 'rocclr' in n: return 'runtime fills / copies'
+    return 'ATen elementwise / pooling / reductions'
+cats = collections.defaultdict(lambda: [0, 0])
+for n, (d, c) in agg.items():
+    cats[cat(n)][0] += d; cats[cat(n)][1] += c
+print("--- by category")
+for n, (d, c) in sorted(cats.items(), key=lambda kv: -kv[1][0]):
+    print(f"{d/1e6/nsteps:8.3f} ms/step {c/nsteps:7.1f} launches  {n}")
