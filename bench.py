@@ -34,7 +34,7 @@ BF16_DENSE_PEAK_TFLOPS = 2500.0
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=30)
+    p.add_argument("--steps", type=int, default=50)
     p.add_argument("--warmup", type=int, default=10)
     p.add_argument("--batch-per-gpu", type=int, default=32)
     p.add_argument("--img", type=int, default=224)

@@ -279,6 +279,35 @@ def ema_scalars(m: float) -> Tuple[np.float32, np.float32]:
 
 
 # --------------------------------------------------------------------------
+# a17: optimizer step of the training loop        main.py:467-477, :640-642
+# --------------------------------------------------------------------------
+def sgd_momentum_step(params: Sequence[torch.Tensor], grads: Sequence[Optional[torch.Tensor]],
+                      bufs: Sequence[Optional[torch.Tensor]], lr: float, momentum: float, weight_decay: float):
+    """torch.optim.SGD(params, lr, momentum, weight_decay) as the reference builds it (dampening 0, no Nesterov),
+    one step, restated on the public algorithm of torch/optim/sgd.py:
+        g' = g + wd * p ;  buf = g' on the first step, else buf * momentum + g' ;  p = p - lr * buf
+    A parameter without gradient is left alone.  Returns (new params, new bufs).  Evaluated in float64 and rounded
+    to fp32 once per statement, which is what a fused multiply-add does up to double rounding (so GPU / CPU torch
+    kernels agree with it to 1 ulp, not necessarily bit for bit)."""
+    out_p, out_b = [], []
+    for p, g, b in zip(params, grads, bufs):
+        if g is None:
+            out_p.append(p.clone()); out_b.append(None if b is None else b.clone())
+            continue
+        p64, g64 = p.double(), g.double()
+        if weight_decay != 0:
+            g64 = (g64 + float(np.float32(weight_decay)) * p64).float().double()
+        if momentum != 0:
+            b64 = g64 if b is None else ((b.double() * float(np.float32(momentum))).float().double() + g64).float().double()
+            out_b.append(b64.float())
+            g64 = b64
+        else:
+            out_b.append(None)
+        out_p.append((p64 - float(np.float32(lr)) * g64).float())
+    return out_p, out_b
+
+
+# --------------------------------------------------------------------------
 # a13: queue enqueue with wrap-around                    builder.py:569-587
 # --------------------------------------------------------------------------
 def dequeue_and_enqueue(queue: torch.Tensor, ptr: int, keys: torch.Tensor) -> Tuple[torch.Tensor, int]:

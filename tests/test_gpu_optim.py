@@ -82,6 +82,24 @@ def test_flat_sgd_is_bit_identical_to_torch_sgd(momentum, wd):
         assert torch.equal(sd["state"][k]["momentum_buffer"], ref.state_dict()["state"][k]["momentum_buffer"])
 
 
+def test_flat_sgd_matches_cpu_oracle():
+    """cp2_sgd_flat against the CPU restatement of torch's SGD (oracle.sgd_momentum_step), <= 1 ulp."""
+    from oracle import cp2_oracle as O
+    m = small_model(amp_dtype=torch.bfloat16, channels_last=True)
+    opt = FlatSGD(m, 0.05, momentum=0.9, weight_decay=5e-4)
+    ps = list(m.encoder_q.parameters())
+    cur = [p.detach().cpu().clone() for p in ps]
+    bufs = [None] * len(ps)
+    for step in range(3):
+        grads = fake_grads(ps, 100 + step)
+        for p, g in zip(ps, grads):
+            p.grad = None if g is None else g.clone()
+        opt.step()
+        cur, bufs = O.sgd_momentum_step(cur, [None if g is None else g.cpu() for g in grads], bufs, 0.05, 0.9, 5e-4)
+        for p, c in zip(ps, cur):
+            assert torch.allclose(p.detach().cpu(), c, rtol=2e-7, atol=1e-9), step
+
+
 def test_query_shadow_follows_foreign_parameter_changes():
     """Any in-place change of a parameter that did not come from FlatSGD (load_state_dict, manual init) is noticed
     at the next forward and the bf16 image is rebuilt."""

@@ -167,3 +167,24 @@ def test_densecl_golden(golden_dir, name):
     assert np.array_equal(qa.numpy(), g["queue_after"]) and ptr == int(g["ptr_after"])
     qa2, ptr2 = O.dequeue_and_enqueue(T(g["queue2_before"]), 0, T(g["k_local_pooled"]))
     assert np.array_equal(qa2.numpy(), g["queue2_after"]) and ptr2 == int(g["ptr2_after"])
+
+
+def test_sgd_restatement_matches_torch_sgd_on_cpu():
+    """oracle.sgd_momentum_step against torch.optim.SGD itself (the optimizer the reference constructs, main.py:467-477)
+    on CPU: three steps with momentum and weight decay, one parameter without gradient; <= 1 ulp."""
+    import torch
+    from oracle import cp2_oracle as O
+    torch.manual_seed(0)
+    ps = [torch.randn(7, 5), torch.randn(64), torch.randn(3, 3, 2, 2)]
+    ref = [torch.nn.Parameter(p.clone()) for p in ps]
+    opt = torch.optim.SGD(ref, lr=0.03, momentum=0.9, weight_decay=1e-4)
+    cur, bufs = [p.clone() for p in ps], [None, None, None]
+    for step in range(3):
+        grads = [torch.randn_like(p) for p in ps]
+        grads[1] = None if step == 1 else grads[1]
+        for r, g in zip(ref, grads):
+            r.grad = None if g is None else g.clone()
+        opt.step()
+        cur, bufs = O.sgd_momentum_step(cur, grads, bufs, 0.03, 0.9, 1e-4)
+        for a, r in zip(cur, ref):
+            assert torch.allclose(a, r.detach(), rtol=2e-7, atol=1e-9), step
