@@ -405,6 +405,9 @@ class MODEL(nn.Module):
 
     # ------------------------------------------------------------------ dispatch
     def forward(self, **kwargs):
+        if self._flat_q_bf16 is not None:       # bf16 weight image in use: rebuild it if a parameter changed elsewhere
+            self.flatten_parameters()
+            self._refresh_query_shadow()
         if self.pretrain_type in (PretrainType.CP2, PretrainType.PROPOSED):
             return self.forward_cp2(**kwargs)
         if self.pretrain_type in (PretrainType.DENSECL, PretrainType.PROPOSED_V2):

@@ -792,6 +792,10 @@ struct DenseArgs {
     // backward
     const float* sample_scal;                    // [B][8]: Sa, Sb, ...
     float grad_scale; float* g_dense;            // [B][CH][P]
+    // forward, split over the query pixels x: S > 1 workgroups share a (sample, key tile) and write partial column
+    // statistics part[7][S][B*P] = {max, sum exp, colsum_a, possum, allsum, best value, best x}; dense_merge_kernel
+    // folds them into the per-key outputs above
+    int splits; float* part;
 };
 
 __device__ __forceinline__ float corr_weight(int64_t pa, int64_t pb, int64_t ra, int64_t rb, float wp, float wr, float wn) {
@@ -827,10 +831,11 @@ __global__ __launch_bounds__(DNT, 2) void dense_fwd_kernel(DenseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DenseLds& L = *reinterpret_cast<DenseLds*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int P = a.P, tiles = (P + 32 * DNW - 1) / (32 * DNW);
+    const int P = a.P, tiles = (P + 32 * DNW - 1) / (32 * DNW), S = a.splits;
     const int item = xcd_work_item(blockIdx.x, gridDim.x);
-    const int n = item / tiles;
-    const int y = ((item % tiles) * DNW + wid) * 32 + r;
+    const int sp = item % S, st = item / S;
+    const int n = st / tiles;
+    const int y = ((st % tiles) * DNW + wid) * 32 + r;
     const bool y_ok = y < P;
     const float* qd = a.qd + (int64_t)n * CH * P;
     const float* kd = a.kd + (int64_t)n * CH * P;
@@ -842,12 +847,14 @@ __global__ __launch_bounds__(DNT, 2) void dense_fwd_kernel(DenseArgs a) {
     float m_run = -INFINITY, s_run = 0.f, a_run = 0.f, pos_run = 0.f, all_run = 0.f, best_v = -INFINITY;
     int best_x = 0;
     const bool vec_ok = (P % 4 == 0) && ((reinterpret_cast<uintptr_t>(qd) & 15u) == 0);
+    const int xs = (((P + S - 1) / S + DKT - 1) / DKT) * DKT;     // this split's query pixels: [x_begin, x_end)
+    const int x_begin = sp * xs, x_end = min(P, x_begin + xs);
     TileRegs<DKT, DNT> rg;
-    tile_load<DKT, DNT>(rg, qd, P, 0, P, tid, vec_ok);
-    for (int x0 = 0; x0 < P; x0 += DKT) {
+    if (x_begin < x_end) tile_load<DKT, DNT>(rg, qd, P, x_begin, P, tid, vec_ok);
+    for (int x0 = x_begin; x0 < x_end; x0 += DKT) {
         __syncthreads();
         tile_store<DKT, DNT>(L.T, rg, tid);
-        if (x0 + DKT < P) tile_load<DKT, DNT>(rg, qd, P, x0 + DKT, P, tid, vec_ok);  // next tile in flight during the MFMAs
+        if (x0 + DKT < x_end) tile_load<DKT, DNT>(rg, qd, P, x0 + DKT, P, tid, vec_ok);  // next tile in flight during the MFMAs
         if (tid < DKT) {
             const int x = x0 + tid;
             L.ma[tid] = x < P ? a.mask_a[(int64_t)n * P + x] : 0.f;
@@ -901,13 +908,48 @@ __global__ __launch_bounds__(DNT, 2) void dense_fwd_kernel(DenseArgs a) {
     if (ov > best_v || (ov == best_v && ox < best_x)) { best_v = ov; best_x = ox; }
     if (y_ok && h == 0) {
         const int64_t o = (int64_t)n * P + y;
-        a.lse[o] = m_run + logf(s_run);
-        a.colsum_a[o] = a_run;
-        a.possum[o] = pos_run;
-        a.allsum[o] = all_run;
-        a.colmax[o] = best_v;
-        a.argx[o] = best_x;
+        if (S == 1) {
+            a.lse[o] = m_run + logf(s_run);
+            a.colsum_a[o] = a_run;
+            a.possum[o] = pos_run;
+            a.allsum[o] = all_run;
+            a.colmax[o] = best_v;
+            a.argx[o] = best_x;
+        } else {
+            const int64_t BP = (int64_t)(gridDim.x / (tiles * S)) * P, arr = (int64_t)S * BP;
+            float* q = a.part + (int64_t)sp * BP + o;
+            q[0] = m_run; q[arr] = s_run; q[2 * arr] = a_run; q[3 * arr] = pos_run; q[4 * arr] = all_run;
+            q[5 * arr] = best_v; q[6 * arr] = __int_as_float(best_x);
+        }
     }
+}
+
+// Fold the S partial column statistics of dense_fwd_kernel (one thread per (sample, key pixel)).  Splits cover
+// increasing x ranges, so "first maximum" (torch.argmax's tie rule) = strictly-greater replacement in split order.
+__global__ __launch_bounds__(256) void dense_merge_kernel(DenseArgs a, int64_t BP) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= BP) return;
+    const int S = a.splits;
+    const int64_t arr = (int64_t)S * BP;
+    const float* q = a.part + o;
+    float M = -INFINITY;
+    for (int sp = 0; sp < S; ++sp) M = fmaxf(M, q[(int64_t)sp * BP]);
+    float s = 0.f, ca = 0.f, pos = 0.f, all = 0.f, bv = -INFINITY;
+    int bx = 0;
+    for (int sp = 0; sp < S; ++sp) {
+        const float* e = q + (int64_t)sp * BP;
+        const float m = e[0];
+        if (m > -INFINITY) s += e[arr] * __expf(m - M);
+        ca += e[2 * arr]; pos += e[3 * arr]; all += e[4 * arr];
+        const float v = e[5 * arr];
+        if (v > bv) { bv = v; bx = __float_as_int(e[6 * arr]); }
+    }
+    a.lse[o] = M + logf(s);
+    a.colsum_a[o] = ca;
+    a.possum[o] = pos;
+    a.allsum[o] = all;
+    a.colmax[o] = bv;
+    a.argx[o] = bx;
 }
 
 // One workgroup per sample: Sa, Sb, the sample's loss, logging means, arg-max label.
@@ -984,10 +1026,11 @@ __global__ __launch_bounds__(DNT, 2) void dense_bwd_kernel(DenseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DenseLds& L = *reinterpret_cast<DenseLds*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int P = a.P, tiles = (P + 32 * DNW - 1) / (32 * DNW);
+    const int P = a.P, tiles = (P + 32 * DNW - 1) / (32 * DNW), S = a.splits;
     const int item = xcd_work_item(blockIdx.x, gridDim.x);
-    const int n = item / tiles;
-    const int x = ((item % tiles) * DNW + wid) * 32 + r;
+    const int sp = item % S, st = item / S;
+    const int n = st / tiles;
+    const int x = ((st % tiles) * DNW + wid) * 32 + r;
     const bool x_ok = x < P;
     const float* qd = a.qd + (int64_t)n * CH * P;
     const float* kd = a.kd + (int64_t)n * CH * P;
@@ -1003,12 +1046,14 @@ __global__ __launch_bounds__(DNT, 2) void dense_bwd_kernel(DenseArgs a) {
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) U[cb] = (f32x16){0};
     const bool vec_ok = (P % 4 == 0) && ((reinterpret_cast<uintptr_t>(kd) & 15u) == 0);
+    const int ys = (((P + S - 1) / S + DKT - 1) / DKT) * DKT;     // this split's key pixels: [y_begin, y_end)
+    const int y_begin = sp * ys, y_end = min(P, y_begin + ys);
     TileRegs<DKT, DNT> rg;
-    tile_load<DKT, DNT>(rg, kd, P, 0, P, tid, vec_ok);
-    for (int y0 = 0; y0 < P; y0 += DKT) {
+    if (y_begin < y_end) tile_load<DKT, DNT>(rg, kd, P, y_begin, P, tid, vec_ok);
+    for (int y0 = y_begin; y0 < y_end; y0 += DKT) {
         __syncthreads();
         tile_store<DKT, DNT>(L.T, rg, tid);
-        if (y0 + DKT < P) tile_load<DKT, DNT>(rg, kd, P, y0 + DKT, P, tid, vec_ok);  // next tile in flight during the MFMAs
+        if (y0 + DKT < y_end) tile_load<DKT, DNT>(rg, kd, P, y0 + DKT, P, tid, vec_ok);  // next tile in flight during the MFMAs
         if (tid < DKT) {
             const int y = y0 + tid;
             L.ma[tid] = y < P ? a.mask_b[(int64_t)n * P + y] : 0.f;   // mb
@@ -1039,12 +1084,23 @@ __global__ __launch_bounds__(DNT, 2) void dense_bwd_kernel(DenseArgs a) {
         }
     }
     if (x_ok) {
-        float* g = a.g_dense + (int64_t)n * CH * P + x;
+        // S > 1: partial gradient of this split, part[sp][B][CH][P]; dense_grad_sum_kernel adds the splits in order
+        float* base = S == 1 ? a.g_dense : a.part + (int64_t)sp * (gridDim.x / (tiles * S)) * CH * P;
+        float* g = base + (int64_t)n * CH * P + x;
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) g[(int64_t)(cb * 32 + rho(reg, h)) * P] = U[cb][reg];
     }
+}
+
+__global__ __launch_bounds__(256) void dense_grad_sum_kernel(const float* __restrict__ part, float* __restrict__ g, int S,
+                                                             int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float acc = part[i];
+    for (int sp = 1; sp < S; ++sp) acc += part[(int64_t)sp * n + i];
+    g[i] = acc;
 }
 
 static int dense_check(const float* qd, const float* kd, const float* ma, const float* mb, const int64_t* pa,
@@ -1057,23 +1113,43 @@ static int dense_check(const float* qd, const float* kd, const float* ma, const 
     return CP2_OK;
 }
 
+// Splits of the query-pixel range per (sample, key tile): enough workgroups for two per CU (the soft-max section of
+// one then overlaps the MFMA chain of the other), never less than one 64-pixel tile per split.
+CP2_API int cp2_dense_num_splits(int B, int P) {
+    if (B <= 0 || P <= 0) return CP2_ERR_SHAPE;
+    const int64_t base = (int64_t)cp2_cdiv(P, 32 * DNW) * B;
+    int s = (int)((512 + base - 1) / base);
+    const int max_s = cp2_cdiv(P, DKT);
+    if (s > max_s) s = max_s;
+    if (s > 16) s = 16;
+    return s < 1 ? 1 : s;
+}
+
 CP2_API int cp2_dense_infonce_fwd(const float* q_dense, const float* k_dense, const float* mask_a,
                                   const float* mask_b, const int64_t* pix_a, const int64_t* pix_b,
                                   const int64_t* reg_a, const int64_t* reg_b, float w_pixel, float w_region,
                                   float w_not, float temperature, float* lse, float* colsum_a, float* possum,
                                   float* allsum, float* colmax, int32_t* argx, float* sample_scal, float* batch_out,
-                                  float* logits_out, int B, int C, int P, void* stream) {
+                                  float* logits_out, float* split_ws, int B, int C, int P, void* stream) {
     int rc = dense_check(q_dense, k_dense, mask_a, mask_b, pix_a, pix_b, reg_a, reg_b, B, C, P, temperature);
     if (rc) return rc;
     if (!lse || !colsum_a || !possum || !allsum || !colmax || !argx || !sample_scal || !batch_out) return CP2_ERR_NULL;
+    const int S = split_ws ? cp2_dense_num_splits(B, P) : 1;
     DenseArgs a{q_dense, k_dense, mask_a, mask_b, pix_a, pix_b, reg_a, reg_b, w_pixel, w_region, w_not,
-                1.0f / temperature, P, lse, colsum_a, possum, allsum, colmax, argx, logits_out, nullptr, 0.f, nullptr};
-    const dim3 grid(cp2_cdiv(P, 32 * DNW) * B);
+                1.0f / temperature, P, lse, colsum_a, possum, allsum, colmax, argx, logits_out, nullptr, 0.f, nullptr,
+                S, split_ws};
+    const dim3 grid(cp2_cdiv(P, 32 * DNW) * B * S);
     const size_t lds = sizeof(DenseLds);
     if (pix_a) hipLaunchKernelGGL(dense_fwd_kernel<true>, grid, dim3(DNT), lds, cp2_stream(stream), a);
     else hipLaunchKernelGGL(dense_fwd_kernel<false>, grid, dim3(DNT), lds, cp2_stream(stream), a);
     rc = cp2_launch_status();
     if (rc) return rc;
+    if (S > 1) {
+        const int64_t BP = (int64_t)B * P;
+        hipLaunchKernelGGL(dense_merge_kernel, dim3((unsigned)((BP + 255) / 256)), dim3(256), 0, cp2_stream(stream), a, BP);
+        rc = cp2_launch_status();
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL(dense_finalize_kernel, dim3(B), dim3(256), 0, cp2_stream(stream), a, sample_scal);
     rc = cp2_launch_status();
     if (rc) return rc;
@@ -1085,16 +1161,23 @@ CP2_API int cp2_dense_infonce_bwd(const float* q_dense, const float* k_dense, co
                                   const float* mask_b, const int64_t* pix_a, const int64_t* pix_b,
                                   const int64_t* reg_a, const int64_t* reg_b, float w_pixel, float w_region,
                                   float w_not, float temperature, const float* lse, const float* sample_scal,
-                                  float grad_scale, float* g_dense, int B, int C, int P, void* stream) {
+                                  float grad_scale, float* g_dense, float* split_ws, int B, int C, int P,
+                                  void* stream) {
     int rc = dense_check(q_dense, k_dense, mask_a, mask_b, pix_a, pix_b, reg_a, reg_b, B, C, P, temperature);
     if (rc) return rc;
     if (!lse || !sample_scal || !g_dense) return CP2_ERR_NULL;
+    const int S = split_ws ? cp2_dense_num_splits(B, P) : 1;
     DenseArgs a{q_dense, k_dense, mask_a, mask_b, pix_a, pix_b, reg_a, reg_b, w_pixel, w_region, w_not,
                 1.0f / temperature, P, const_cast<float*>(lse), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                sample_scal, grad_scale, g_dense};
-    const dim3 grid(cp2_cdiv(P, 32 * DNW) * B);
+                sample_scal, grad_scale, g_dense, S, split_ws};
+    const dim3 grid(cp2_cdiv(P, 32 * DNW) * B * S);
     const size_t lds = sizeof(DenseLds);
     if (pix_a) hipLaunchKernelGGL(dense_bwd_kernel<true>, grid, dim3(DNT), lds, cp2_stream(stream), a);
     else hipLaunchKernelGGL(dense_bwd_kernel<false>, grid, dim3(DNT), lds, cp2_stream(stream), a);
+    rc = cp2_launch_status();
+    if (rc || S == 1) return rc;
+    const int64_t n = (int64_t)B * CH * P;
+    hipLaunchKernelGGL(dense_grad_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cp2_stream(stream), split_ws,
+                       g_dense, S, n);
     return cp2_launch_status();
 }

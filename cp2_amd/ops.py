@@ -405,12 +405,15 @@ def dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temperature: float, ids=
     batch = torch.empty(2, dtype=torch.float32, device=dev)
     res.logits = torch.empty((B, P, P), dtype=torch.float32, device=dev) if want_logits else None
     pa, pb, ra, rb = _ids4(ids)
+    S = lib.cp2_dense_num_splits(B, P)
+    split_ws = torch.empty(7 * S * B * P, dtype=torch.float32, device=dev) if S > 1 else None
     rc = lib.cp2_dense_infonce_fwd(_dev(q_dense, "q_dense", torch.float32), _dev(k_dense, "k_dense", torch.float32),
                                    _dev(mask_a, "mask_a", torch.float32), _dev(mask_b, "mask_b", torch.float32),
                                    pa, pb, ra, rb, float(weights[0]), float(weights[1]), float(weights[2]),
                                    float(temperature), res.lse.data_ptr(), colsum.data_ptr(), possum.data_ptr(),
                                    allsum.data_ptr(), res.colmax.data_ptr(), res.argx.data_ptr(),
-                                   res.sample_scal.data_ptr(), batch.data_ptr(), _opt(res.logits, "logits"), B, C, P, _stream())
+                                   res.sample_scal.data_ptr(), batch.data_ptr(), _opt(res.logits, "logits"),
+                                   split_ws.data_ptr() if split_ws is not None else None, B, C, P, _stream())
     _lib.check(rc, "cp2_dense_infonce_fwd")
     res.loss, res.acc = batch[0], batch[1]
     return res
@@ -422,10 +425,13 @@ def dense_infonce_bwd(q_dense, k_dense, mask_a, mask_b, temperature: float, fwd:
     B, C, P = q_dense.shape
     g = torch.empty_like(q_dense)
     pa, pb, ra, rb = _ids4(ids)
+    S = lib.cp2_dense_num_splits(B, P)
+    split_ws = torch.empty(S * B * C * P, dtype=torch.float32, device=q_dense.device) if S > 1 else None
     rc = lib.cp2_dense_infonce_bwd(_dev(q_dense, "q_dense"), _dev(k_dense, "k_dense"), _dev(mask_a, "mask_a"),
                                    _dev(mask_b, "mask_b"), pa, pb, ra, rb, float(weights[0]), float(weights[1]),
                                    float(weights[2]), float(temperature), fwd.lse.data_ptr(), fwd.sample_scal.data_ptr(),
-                                   float(grad_scale), g.data_ptr(), B, C, P, _stream())
+                                   float(grad_scale), g.data_ptr(), split_ws.data_ptr() if split_ws is not None else None,
+                                   B, C, P, _stream())
     _lib.check(rc, "cp2_dense_infonce_bwd")
     return g
 

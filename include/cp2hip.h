@@ -150,18 +150,25 @@ int cp2_rowkey_infonce_finalize(const float* part_m, const float* part_s, const 
  * Per key pixel outputs [B,P]: lse, colsum_a, possum, allsum, colmax, argx (workspaces kept for backward /
  * logging).  sample_scal [B,8] = {Sa, Sb, loss_n, mean positive score, mean negative score, label at the
  * arg-max pair, 0, 0};  batch_out[2] = {mean_n loss_n, 100 * mean_n label}.
- * logits_out: NULL, or [B,P,P] to also receive the raw logits q.k (only for the logging quantiles).   C = 128. */
+ * logits_out: NULL, or [B,P,P] to also receive the raw logits q.k (only for the logging quantiles).   C = 128.
+ * split_ws: NULL (one workgroup per (sample, 128-key tile) walks all query pixels), or float[7 * S * B * P] with
+ * S = cp2_dense_num_splits(B, P): S workgroups share the walk and a merge kernel folds their partial statistics, so
+ * small B*P still fills the chip. */
+int cp2_dense_num_splits(int B, int P);
 int cp2_dense_infonce_fwd(const float* q_dense, const float* k_dense, const float* mask_a, const float* mask_b,
                           const int64_t* pix_a, const int64_t* pix_b, const int64_t* reg_a, const int64_t* reg_b,
                           float w_pixel, float w_region, float w_not, float temperature, float* lse,
                           float* colsum_a, float* possum, float* allsum, float* colmax, int32_t* argx,
-                          float* sample_scal, float* batch_out, float* logits_out, int B, int C, int P, void* stream);
-/* g_dense [B,C,P] = grad_scale * d (sum_n loss_n) / d q_dense, recomputing the logits tile by tile. */
+                          float* sample_scal, float* batch_out, float* logits_out, float* split_ws, int B, int C,
+                          int P, void* stream);
+/* g_dense [B,C,P] = grad_scale * d (sum_n loss_n) / d q_dense, recomputing the logits tile by tile.
+ * split_ws: NULL, or float[S * B * C * P] with S = cp2_dense_num_splits(B, P): the key-pixel range is shared by S
+ * workgroups and their partial gradients are added in split order (deterministic). */
 int cp2_dense_infonce_bwd(const float* q_dense, const float* k_dense, const float* mask_a, const float* mask_b,
                           const int64_t* pix_a, const int64_t* pix_b, const int64_t* reg_a, const int64_t* reg_b,
                           float w_pixel, float w_region, float w_not, float temperature, const float* lse,
-                          const float* sample_scal, float grad_scale, float* g_dense, int B, int C, int P,
-                          void* stream);
+                          const float* sample_scal, float grad_scale, float* g_dense, float* split_ws, int B, int C,
+                          int P, void* stream);
 
 /* ---- a15: logging quantiles without a sort ---------------- tools/correlation_mapping.py:16-53, builder.py:1399-1406
  * out[j, r] = torch.nanquantile(kept elements of row r, q[j]) with linear interpolation (exact order statistics by
