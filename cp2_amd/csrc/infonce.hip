@@ -582,11 +582,13 @@ __global__ __launch_bounds__(256) void rowkey_finalize_kernel(RowKeyFinArgs a) {
 }
 
 // Many-splits form (instance loss: R = batch size, S = 256 splits): a serial loop over S per row is pure
-// load latency (measured 204-236 us), so here 8 "split lanes" share each row: thread = (row r of 32, lane sl of 8),
-// each lane reduces the splits s = sl, sl+8, ... and the 8 partial results meet in LDS.  grid = (R/32, CH/8).
-constexpr int FS_SL = 8, FS_CPB = 8;
+// load latency (measured 204-236 us), so here FS_SL "split lanes" share each row: thread = (row r of 32, lane sl),
+// each lane reduces the splits s = sl, sl+FS_SL, ... and the partial results meet in LDS.  grid = (R/32, CH/8).
+// (32 split lanes: with 8, the three dependent passes over S = 256 partials were 32 serial load rounds each -- 33 us for
+// the 4 MB of partials of the instance loss.)
+constexpr int FS_SL = 32, FS_CPB = 8;
 
-__global__ __launch_bounds__(256) void rowkey_finalize_spar_kernel(RowKeyFinArgs a) {
+__global__ __launch_bounds__(32 * FS_SL) void rowkey_finalize_spar_kernel(RowKeyFinArgs a) {
     __shared__ float red[FS_SL][32];
     __shared__ int redi[FS_SL][32];
     __shared__ float red2[FS_CPB][FS_SL][32];
@@ -644,6 +646,7 @@ __global__ __launch_bounds__(256) void rowkey_finalize_spar_kernel(RowKeyFinArgs
 #pragma unroll
     for (int i = 0; i < FS_CPB; ++i) red2[i][sl][r] = acc[i];
     __syncthreads();
+    if (sl >= FS_CPB) return;
     float tot = 0.f;                       // split lane sl finishes channel c0 + sl
 #pragma unroll
     for (int j = 0; j < FS_SL; ++j) tot += red2[sl][j][r];
@@ -765,7 +768,7 @@ CP2_API int cp2_rowkey_infonce_finalize(const float* part_m, const float* part_s
     RowKeyFinArgs a{part_m, part_s, part_cnt, part_U, nsplit, extras, NE, 1.0f / temperature, grad_scale,
                     R, RP, d_sn, d_sx, d_sc, lse, loss_rows, cnt_gt, drows, dE};
     if (nsplit >= 16)
-        hipLaunchKernelGGL(rowkey_finalize_spar_kernel, dim3(cp2_cdiv(R, 32), drows ? CH / FS_CPB : 1), dim3(256), 0,
+        hipLaunchKernelGGL(rowkey_finalize_spar_kernel, dim3(cp2_cdiv(R, 32), drows ? CH / FS_CPB : 1), dim3(32 * FS_SL), 0,
                            cp2_stream(stream), a);
     else
         hipLaunchKernelGGL(rowkey_finalize_kernel, dim3(cp2_cdiv(R, 64), drows ? CH / (4 * FIN_CPW) : 1), dim3(256), 0,
