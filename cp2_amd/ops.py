@@ -393,7 +393,7 @@ def _ids4(ids):
 
 
 def dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temperature: float, ids=None,
-                      weights=(1.0, 1.0, 1.0), want_logits: bool = False) -> DenseResult:
+                      weights=(1.0, 1.0, 1.0), want_logits: bool = False, split: bool = True) -> DenseResult:
     lib = _lib.load()
     B, C, P = q_dense.shape
     dev = q_dense.device
@@ -405,7 +405,7 @@ def dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temperature: float, ids=
     batch = torch.empty(2, dtype=torch.float32, device=dev)
     res.logits = torch.empty((B, P, P), dtype=torch.float32, device=dev) if want_logits else None
     pa, pb, ra, rb = _ids4(ids)
-    S = lib.cp2_dense_num_splits(B, P)
+    S = lib.cp2_dense_num_splits(B, P) if split else 1
     split_ws = torch.empty(7 * S * B * P, dtype=torch.float32, device=dev) if S > 1 else None
     rc = lib.cp2_dense_infonce_fwd(_dev(q_dense, "q_dense", torch.float32), _dev(k_dense, "k_dense", torch.float32),
                                    _dev(mask_a, "mask_a", torch.float32), _dev(mask_b, "mask_b", torch.float32),
@@ -420,12 +420,12 @@ def dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temperature: float, ids=
 
 
 def dense_infonce_bwd(q_dense, k_dense, mask_a, mask_b, temperature: float, fwd: DenseResult, grad_scale: float,
-                      ids=None, weights=(1.0, 1.0, 1.0)) -> torch.Tensor:
+                      ids=None, weights=(1.0, 1.0, 1.0), split: bool = True) -> torch.Tensor:
     lib = _lib.load()
     B, C, P = q_dense.shape
     g = torch.empty_like(q_dense)
     pa, pb, ra, rb = _ids4(ids)
-    S = lib.cp2_dense_num_splits(B, P)
+    S = lib.cp2_dense_num_splits(B, P) if split else 1
     split_ws = torch.empty(S * B * C * P, dtype=torch.float32, device=q_dense.device) if S > 1 else None
     rc = lib.cp2_dense_infonce_bwd(_dev(q_dense, "q_dense"), _dev(k_dense, "k_dense"), _dev(mask_a, "mask_a"),
                                    _dev(mask_b, "mask_b"), pa, pb, ra, rb, float(weights[0]), float(weights[1]),

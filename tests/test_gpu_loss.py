@@ -284,3 +284,34 @@ def test_densecl_local_positives_and_losses_golden(golden_dir, name):
     assert_close(loss_global, g["loss_global"], 2e-5, what="loss_global")
     assert_close((1 - lmbd) * loss_global + lmbd * loss_local, g["loss"], 2e-5, what="loss")
     assert torch.isfinite(ql.grad).all() and float(ql.grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize("B,P", [(2, 196), (1, 132), (3, 1024), (5, 70)])
+def test_dense_range_split_equals_single_walk_with_weights(B, P):
+    """The dense kernels with the query / key range shared by several workgroups (cp2_dense_num_splits > 1, merge and
+    partial-sum kernels) against the single-walk form (pinned by the goldens), with correspondence weights on:
+    statistics and gradients to 2e-6 relative, arg-max indices exact."""
+    from cp2_amd import _lib, ops
+    assert _lib.load().cp2_dense_num_splits(B, P) > 1
+    g = torch.Generator(DEV).manual_seed(B * 7 + P)
+    qd = torch.nn.functional.normalize(torch.randn(B, 128, P, device=DEV, generator=g), dim=1)
+    kd = torch.nn.functional.normalize(torch.randn(B, 128, P, device=DEV, generator=g), dim=1)
+    ma = (torch.rand(B, P, device=DEV, generator=g) > 0.4).float()
+    mb = (torch.rand(B, P, device=DEV, generator=g) > 0.5).float()
+    pix_a = torch.randint(1, P // 2, (B, P), device=DEV, generator=g)
+    pix_b = torch.randint(1, P // 2, (B, P), device=DEV, generator=g)
+    reg_a, reg_b = pix_a // 4, pix_b // 4                       # region 0 = unknown for some pixels
+    ids, w = (pix_a, pix_b, reg_a, reg_b), (2.0, 0.5, 0.25)
+    res = {}
+    for split in (True, False):
+        fw = ops.dense_infonce_fwd(qd, kd, ma, mb, 0.7, ids=ids, weights=w, want_logits=True, split=split)
+        gq = ops.dense_infonce_bwd(qd, kd, ma, mb, 0.7, fw, 0.3, ids=ids, weights=w, split=split)
+        res[split] = (fw, gq)
+    a, b = res[True], res[False]
+    assert torch.equal(a[0].argx, b[0].argx) and torch.equal(a[0].colmax, b[0].colmax)
+    assert torch.equal(a[0].logits, b[0].logits)
+    for name in ("lse", "sample_scal"):
+        x, y = getattr(a[0], name), getattr(b[0], name)
+        assert torch.allclose(x, y, rtol=2e-6, atol=2e-6, equal_nan=True), name
+    assert torch.allclose(a[0].loss, b[0].loss, rtol=2e-6, atol=2e-6) and torch.equal(a[0].acc, b[0].acc)
+    assert (a[1] - b[1]).abs().max().item() <= 2e-6 * b[1].abs().max().item() + 1e-9
