@@ -98,9 +98,12 @@ class _Conv1x1Fn(torch.autograd.Function):
     MIOpen's implicit-GEMM solvers lose to hipBLASLt on the data gradient of almost every such layer of the ResNet
     (MI355X, graph-replayed launches: 393 -> 263 us summed over the distinct ResNet-50 shapes) and on the forward of
     the wide low-resolution ones, while hipBLASLt's [Co, M] x [M, Ci] weight gradient is 4-15x slower at large M:
-    forward and data gradient pick the GEMM per shape (`mm_fwd`, `mm_dgrad`), the weight gradient stays with MIOpen.
+    forward and data gradient pick the GEMM per shape (`mm_fwd`, `mm_dgrad`); the weight gradient is the hand-written
+    cp2_wgrad1x1 (csrc/wgrad.hip: deterministic, fp32 output, at or above MIOpen's speed on every ResNet-50 shape).
     `weight` is the fp32 master (receives the fp32 gradient, as autocast's cast node would deliver it), `shadow` its
     bf16 image."""
+
+    hip_wgrad = True         # weight gradient by cp2_wgrad1x1 (False: MIOpen) -- A/B switch
 
     @staticmethod
     def forward(ctx, x, weight, shadow, bias, mm_fwd, mm_dgrad):
@@ -128,12 +131,20 @@ class _Conv1x1Fn(torch.autograd.Function):
         dx = None
         if need_dx and ctx.mm_dgrad:
             dx = torch.mm(dy.permute(0, 2, 3, 1).reshape(-1, co), w.reshape(co, C)).view(N, H, W, C).permute(0, 3, 1, 2)
-        rest = torch.ops.aten.convolution_backward(dy, x, w, [co] if need_db else None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
-                                                   [need_dx and dx is None, need_dw, bool(need_db)])
-        if need_dx and dx is None:
-            dx = rest[0]
-        dw = rest[1].to(torch.float32) if need_dw else None
-        db = rest[2].to(torch.float32) if need_db else None
+        dw = None
+        if need_dw and _Conv1x1Fn.hip_wgrad and _bn_ops.wgrad1x1_supported(co, C):
+            dw = _bn_ops.wgrad1x1(dy, x)          # deterministic split-K on the matrix cores, fp32 result (csrc/wgrad.hip)
+        want = [need_dx and dx is None, need_dw and dw is None, bool(need_db)]
+        if any(want):
+            rest = torch.ops.aten.convolution_backward(dy, x, w, [co] if need_db else None, [1, 1], [0, 0], [1, 1], False,
+                                                       [0, 0], 1, want)
+            if want[0]:
+                dx = rest[0]
+            if want[1]:
+                dw = rest[1].to(torch.float32)
+            db = rest[2].to(torch.float32) if need_db else None
+        else:
+            db = None
         return dx, dw, None, db, None, None
 
 
@@ -144,6 +155,7 @@ class Conv2d(nn.Conv2d):
 
     shadow_weight = None
     gemm_1x1 = True          # class-wide switch (A/B)
+    graph_step = False       # set by engine.TrainStep(use_graph=True): warm-up steps must take the path the capture takes
 
     def forward(self, x):
         w = self.shadow_weight
@@ -155,7 +167,7 @@ class Conv2d(nn.Conv2d):
                 if not (torch.is_grad_enabled() and (self.weight.requires_grad or x.requires_grad)):
                     if mm_fwd:                      # gradient-free forward (key encoder): no autograd node needed
                         return _Conv1x1Fn.forward(_NoCtx, x, None, w, self.bias, True, False)
-                elif torch.cuda.is_current_stream_capturing():
+                elif Conv2d.graph_step or torch.cuda.is_current_stream_capturing():
                     # with autograd the Python-side Function costs ~0.1 ms of host time per layer and step: worth it
                     # only when the step is being captured into a hipGraph (host time is then paid once)
                     return _Conv1x1Fn.apply(x, self.weight, w, self.bias, mm_fwd, ci >= 128)

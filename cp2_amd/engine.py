@@ -69,6 +69,11 @@ class TrainStep:
     def __init__(self, model, optimizer, use_graph: bool = False, warmup_steps: int = 3):
         self.model, self.optimizer = model, optimizer
         self.use_graph, self.warmup_steps = use_graph, warmup_steps
+        if use_graph:
+            # libraries initialise per shape on first use (hipBLASLt refuses to do that while a stream is capturing): the
+            # eager warm-up steps must run exactly the kernels the capture will record
+            from .encoder import Conv2d
+            Conv2d.graph_step = True
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.static: Dict[str, torch.Tensor] = {}
         self.static_loss = None

@@ -522,3 +522,30 @@ def bn_bwd(x, dy, y, weight, stats, relu: bool, want_dres: bool):
     if want_dres and not relu:
         dres = dy
     return dx, dres, ws[2 * G + 3], ws[2 * G + 4]
+
+
+# ---------------------------------------------------------------- encoder fast path: 1x1 convolution weight gradient
+def wgrad1x1_supported(co: int, ci: int) -> bool:
+    return co % 64 == 0 and ci % 64 == 0
+
+
+def wgrad1x1(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """dW [CO, CI, 1, 1] fp32 = sum over (n, h, w) of dy[n, :, h, w] (x) x[n, :, h, w] for channels-last bf16 NCHW
+    tensors (csrc/wgrad.hip)."""
+    lib = _lib.load()
+    N, CO, H, W = dy.shape
+    CI = x.shape[1]
+    M = N * H * W
+    if not (dy.is_contiguous(memory_format=torch.channels_last) and x.is_contiguous(memory_format=torch.channels_last)):
+        raise _lib.Cp2LibraryError("wgrad1x1: channels-last tensors expected")
+    S = lib.cp2_wgrad1x1_num_splits(M, CO, CI)
+    if S < 0:
+        _lib.check(S, "cp2_wgrad1x1_num_splits")
+    dw = torch.empty((CO, CI, 1, 1), dtype=torch.float32, device=dy.device)
+    part = torch.empty(S * CO * CI, dtype=torch.float32, device=dy.device) if S > 1 else dw
+    if not (dy.is_cuda and x.is_cuda and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and x.shape[0] == N
+            and x.shape[2:] == dy.shape[2:]):
+        raise _lib.Cp2LibraryError("wgrad1x1: bf16 GPU tensors of matching batch / spatial size expected")
+    rc = lib.cp2_wgrad1x1(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), part.data_ptr(), M, CO, CI, _stream())
+    _lib.check(rc, "cp2_wgrad1x1")
+    return dw

@@ -214,6 +214,13 @@ int cp2_bn_bwd(const void* x, const void* dy, const void* y, const float* weight
                const float* save_invstd, int relu, void* dx, void* dres, float* dgamma, float* dbeta, float* part,
                float* coef, int M, int C, void* stream);
 
+/* ---- encoder fast path (not a reference call site): weight gradient of a 1x1 stride-1 convolution ---------------
+ * dw[co][ci] = sum_m dy[m][co] * x[m][ci];  dy: [M, CO] bf16, x: [M, CI] bf16 (channels-last activations viewed as
+ * matrices, 16-byte aligned), dw: [CO, CI] fp32;  CO % 64 == 0, CI % 64 == 0.  part: float[S * CO * CI] with
+ * S = cp2_wgrad1x1_num_splits(M, CO, CI); partial tiles are added in split order (deterministic, no atomics). */
+int cp2_wgrad1x1_num_splits(int M, int CO, int CI);
+int cp2_wgrad1x1(const void* dy, const void* x, float* dw, float* part, int M, int CO, int CI, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

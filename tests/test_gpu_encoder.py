@@ -66,3 +66,20 @@ def test_conv2d_module_routes_1x1_and_keeps_other_layers():
     c3.shadow_weight = c3.weight.detach().to(torch.bfloat16)
     x3 = torch.randn(2, 64, 8, 8, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     assert type(c3(x3).grad_fn).__name__ != "_Conv1x1FnBackward"
+
+
+@pytest.mark.parametrize("N,H,W,co,ci", [(2, 7, 7, 64, 64), (8, 14, 14, 512, 2048), (4, 28, 28, 128, 512), (2, 56, 56, 64, 256),
+                                         (3, 5, 3, 192, 320), (32, 14, 14, 1024, 256), (1, 1, 1, 128, 128), (5, 9, 11, 256, 128)])
+def test_wgrad1x1_matches_fp32_matmul(N, H, W, co, ci):
+    """cp2_wgrad1x1 (transposing LDS reads + bf16 MFMA, fp32 accumulation, deterministic split-K) against the fp32
+    matmul of the same bf16 operands: products are exact in fp32, only the summation order differs -> 2e-5 of max."""
+    from cp2_amd import ops
+    torch.manual_seed(co + ci + H)
+    dy = torch.randn(N, co, H, W, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x = torch.randn(N, ci, H, W, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dw = ops.wgrad1x1(dy, x)
+    assert dw.shape == (co, ci, 1, 1) and dw.dtype == torch.float32
+    ref = dy.permute(0, 2, 3, 1).reshape(-1, co).double().t() @ x.permute(0, 2, 3, 1).reshape(-1, ci).double()
+    err = (dw.view(co, ci).double() - ref).abs().max().item()
+    assert err <= 2e-5 * ref.abs().max().item() + 1e-6, err
+    assert torch.equal(dw, ops.wgrad1x1(dy, x))                 # run-to-run identical
