@@ -51,8 +51,9 @@ def parse():
     p.add_argument("--flat-sgd", default="on", choices=["on", "off"],
                    help="optimizer step as one HIP launch on the flat parameter buffer (off: torch.optim.SGD) (A/B)")
     p.add_argument("--fused-bn", default="on", choices=["on", "off"], help="encoder fast path: fused BN(+add)(+ReLU) kernels (A/B)")
-    p.add_argument("--overlap", default="auto", choices=["auto", "on", "off"],
-                   help="key branch (EMA, shuffle all-gathers, key encoder) on a side HIP stream; auto = when N > 1")
+    p.add_argument("--overlap", default="auto", choices=["auto", "gather", "on", "off"],
+                   help="side HIP stream for the key branch: gather = EMA + shuffle all-gather only (auto when N > 1), "
+                        "on = the key encoder too, off = serial (auto at N = 1)")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     p.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     p.add_argument("--cpu-batch", type=int, default=8)
@@ -129,7 +130,7 @@ def main():
     # the EMA is hoisted in front of the (graph-captured) rest of the step so each of its launches can be
     # bracketed by HIP events on the launch stream; it reads theta_q after the previous optimizer step and
     # runs before the key encoder, exactly where the reference's call does (builder.py:1272).
-    model.overlap_key_branch = {"auto": None, "on": True, "off": False}[args.overlap]
+    model.overlap_key_branch = {"auto": None, "gather": "gather", "on": True, "off": False}[args.overlap]
     model.ema_in_forward = False
     ema_events = []
 

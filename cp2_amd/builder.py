@@ -246,7 +246,7 @@ class MODEL(nn.Module):
         self._flat_q_bf16 = None         # bf16 image of the query weights, written by optim.FlatSGD (enable_query_shadow)
         self._q_shadow_version = None
         self.ema_in_forward = True       # False: the caller runs _momentum_update_key_encoder() itself before forward
-        self.overlap_key_branch = None   # key branch on a side stream: None = only when world size > 1 (no gain at N=1)
+        self.overlap_key_branch = None   # None: "gather" when world size > 1, off at 1; see forward_cp2
         self._side_stream = None
         self.key_forward_graph = True    # replay the (gradient-free) key encoder forward from a hipGraph after warm-up
         self._key_graph = None
@@ -442,25 +442,36 @@ class MODEL(nn.Module):
         self.correlation_ious.append(iou)
         self.masked_correlation_ious.append(iou_masked)
 
-        # The key branch (EMA -> shuffle-BN all-gather -> key encoder -> un-shuffle all-gather) does not depend on
-        # the query encoder, so it runs on a side HIP stream: its RCCL all-gathers and small kernels overlap with
-        # the query forward on the main stream (reference order builder.py:1260-1277 is serial).
+        # The key branch (EMA -> shuffle-BN all-gather -> key encoder -> un-shuffle all-gather) does not depend on the
+        # query encoder (reference order builder.py:1260-1277 is serial).  overlap_key_branch:
+        #   "gather" (default when world size > 1): EMA + the image all-gather and row gather run on a side HIP stream
+        #            and overlap the query forward; the key encoder itself follows on the main stream (two compute-heavy
+        #            branches interleaved on one GPU measured 4 % SLOWER than back to back);
+        #   True: the whole key branch on the side stream;   False (default at world size 1): everything in order.
         self.flatten_parameters()        # on the main stream, before the fork: it re-homes the query parameters too
         self._refresh_query_shadow()
         cur = torch.cuda.current_stream()
-        overlap = cdist.world_size() > 1 if self.overlap_key_branch is None else self.overlap_key_branch
-        side = self._key_stream() if overlap else cur
+        mode = self.overlap_key_branch
+        if mode is None:
+            mode = "gather" if cdist.world_size() > 1 else False
+        side = self._key_stream() if mode else cur
         if side is not cur:
             side.wait_stream(cur)
+        k = None
         with torch.cuda.stream(side), torch.no_grad():
             if self.ema_in_forward:
                 self._momentum_update_key_encoder()
             img_b, idx_unshuffle = self._batch_shuffle_ddp(img_b, idx_shuffle)
-            k = self._encode_key(img_b)
-            k = self._batch_unshuffle_ddp(k, idx_unshuffle)
+            if mode != "gather":
+                k = self._batch_unshuffle_ddp(self._encode_key(img_b), idx_unshuffle)
         q = self._encode(self.encoder_q, img_a).float()                          # queries: b x C x h x w
         if side is not cur:
             cur.wait_stream(side)
+        if k is None:
+            with torch.no_grad():
+                if side is not cur:
+                    img_b.record_stream(cur)          # allocated on the side stream, read on this one
+                k = self._batch_unshuffle_ddp(self._encode_key(img_b), idx_unshuffle)
 
         out = CF.cp2_loss_section(q, k, mask_a, mask_b, self.queue, temp_global=self.temp_global,
                                   temp_local=self.temp_local, lmbd_dense=self.lmbd_dense_loss,

@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, mode="torch-sgd"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import sys
     sys.path.insert(0, ROOT)
@@ -40,9 +40,16 @@ def _worker(rank, world, port, out_dir):
         model.encoder_k.to(memory_format=torch.channels_last)
         ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], output_device=0, broadcast_buffers=False,
                                                         gradient_as_bucket_view=True)
-        opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+        steps = 3
+        if mode == "torch-sgd":
+            opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+        else:        # the bench / main.py configuration: FlatSGD, enough steps for the key-forward hipGraph to be replayed
+            from cp2_amd.optim import FlatSGD
+            opt = FlatSGD(ddp, 0.01, momentum=0.9, weight_decay=1e-4)
+            model.overlap_key_branch = {"flat-gather": None, "flat-branch": True}[mode]
+            steps = 6
         b = 6
-        for step in range(3):
+        for step in range(steps):
             batch = synthetic.make_batch(b, 64, 64, dev, seed=100 * rank + step)     # different data on each rank
             loss = ddp(visualize=False, step=step, new_epoch=False, **batch)
             opt.zero_grad(set_to_none=True)
@@ -50,9 +57,11 @@ def _worker(rank, world, port, out_dir):
             opt.step()
             assert torch.isfinite(loss)
         assert model._side_stream is not None                                     # key branch ran on the side stream
+        if mode != "torch-sgd":
+            assert model._key_graph is not None and any(e["graph"] is not None for e in model._key_graph.entries.values())
         torch.cuda.synchronize()
         g = model.encoder_q.backbone.conv1.weight.grad.detach().float().cpu()
-        torch.save({"queue": model.queue.cpu(), "ptr": int(model.queue_ptr), "grad": g,
+        torch.save({"queue": model.queue.cpu(), "ptr": int(model.queue_ptr), "grad": g, "steps": steps,
                     "w": model.encoder_q.backbone.conv1.weight.detach().cpu(),
                     "k": model.encoder_k.backbone.conv1.weight.detach().cpu()}, os.path.join(out_dir, f"r{rank}.pt"))
         dist.barrier()
@@ -61,11 +70,12 @@ def _worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(300)
-def test_two_ranks_one_device_gloo(tmp_path):
+@pytest.mark.parametrize("mode", ["torch-sgd", "flat-gather", "flat-branch"])
+def test_two_ranks_one_device_gloo(tmp_path, mode):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), mode), nprocs=world, join=True)
     r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
-    assert r0["ptr"] == r1["ptr"] == (3 * 2 * 6) % 256
+    assert r0["ptr"] == r1["ptr"] == (r0["steps"] * 2 * 6) % 256
     assert torch.equal(r0["queue"], r1["queue"])                  # identical enqueue on every rank, in rank order
     assert torch.equal(r0["grad"], r1["grad"]) and float(r0["grad"].abs().max()) > 0   # DDP-averaged gradients
     assert torch.equal(r0["w"], r1["w"]) and torch.equal(r0["k"], r1["k"])             # replicas stay in lock-step
