@@ -195,7 +195,8 @@ def main():
         "config": {"workload": f"BASELINE configs[1]: ResNet-50 + FCN(contrast) head OS16, {hw}x{hw} copy-paste pairs, "
                                f"queue={args.queue}, {b} img/GPU, encoders bf16 autocast channels-last, loss kernels fp32 (f32 MFMA), "
                                f"SGD(0.9, wd 1e-4), random-init weights",
-                   "global_batch": b * world, "parallelism": f"dp{world}", "hipgraph": bool(use_graph),
+                   "global_batch": b * world, "parallelism": f"dp{world}",
+                   "hipgraph": bool(use_graph and runner.graph is not None), "hipgraph_fallback": runner.fallback_reason,
                    "final_loss": round(loss_val, 4)},
         "roofline": {"kernel": "ema_flat_kernel (momentum update of the key encoder, builder.py:557-567)", "bound": "hbm",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

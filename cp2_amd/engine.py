@@ -66,9 +66,15 @@ class ForwardGraph:
 
 
 class TrainStep:
-    def __init__(self, model, optimizer, use_graph: bool = False, warmup_steps: int = 3):
+    """verify (graph mode): before the first replay is trusted, one eager forward/backward on the same batch from the
+    same state provides reference gradients; the first replay's gradients must agree tensor by tensor (MIOpen
+    weight-gradient solvers have been seen to return garbage under replay).  On disagreement, or
+    if the capture itself fails, the state is rolled back and the step continues eagerly (`self.fallback_reason`)."""
+
+    def __init__(self, model, optimizer, use_graph: bool = False, warmup_steps: int = 3, verify: bool = True):
         self.model, self.optimizer = model, optimizer
-        self.use_graph, self.warmup_steps = use_graph, warmup_steps
+        self.use_graph, self.warmup_steps, self.verify = use_graph, warmup_steps, verify
+        self.fallback_reason = None
         if use_graph:
             # libraries initialise per shape on first use (hipBLASLt refuses to do that while a stream is capturing): the
             # eager warm-up steps must run exactly the kernels the capture will record
@@ -118,14 +124,92 @@ class TrainStep:
                 self._eager_calls += 1
                 self.step_idx += 1
                 return loss.detach()
-            self._inner().flush_logs()
-            self.graph = torch.cuda.CUDAGraph()
-            self.optimizer.zero_grad(set_to_none=True)
-            with torch.cuda.graph(self.graph):
-                self.static_loss = self._eager(self.static, self.static_idx).detach()
+            return self._capture_and_first_replay(batch, n_all, dev)
         for k in INPUT_KEYS:
             self.static[k].copy_(batch[k])
         self.static_idx.copy_(self._shuffle_index(n_all, dev))
         self.graph.replay()
+        self.step_idx += 1
+        return self.static_loss
+
+    # ------------------------------------------------------------------ capture, checked against an eager step
+    def _snapshot(self):
+        import copy
+        inner = self._inner()
+        return {"model": {k: v.detach().clone() for k, v in inner.state_dict().items()},
+                "optim": copy.deepcopy(self.optimizer.state_dict()),
+                "lists": (len(inner._pending_logs), len(inner.correlation_ious), len(inner.masked_correlation_ious))}
+
+    def _restore(self, snap, optimizer_too: bool):
+        inner = self._inner()
+        inner.load_state_dict(snap["model"])
+        if optimizer_too:
+            self.optimizer.load_state_dict(snap["optim"])
+        n_logs, n_a, n_b = snap["lists"]
+        del inner._pending_logs[n_logs:], inner.correlation_ious[n_a:], inner.masked_correlation_ious[n_b:]
+        for m in inner.modules():                  # state_dict() folded the lazy BN batch counters into the snapshot
+            if hasattr(m, "_pending_batches"):
+                m._pending_batches = 0
+
+    def _give_up_graph(self, reason, batch):
+        import warnings
+        from .encoder import Conv2d
+        warnings.warn(f"TrainStep: hipGraph step disabled ({reason}); continuing eagerly")
+        self.fallback_reason, self.use_graph, self.graph = reason, False, None
+        Conv2d.graph_step = False
+        loss = self._eager(batch)
+        self.step_idx += 1
+        return loss.detach()
+
+    def _capture_and_first_replay(self, batch, n_all, dev):
+        inner = self._inner()
+        inner.flush_logs()
+        for k in INPUT_KEYS:
+            self.static[k].copy_(batch[k])
+        self.static_idx.copy_(self._shuffle_index(n_all, dev))
+        params = [p for p in inner.parameters() if p.requires_grad]
+        ref_grads = ref_loss = None
+        snap = None
+        if self.verify:
+            side = torch.cuda.Stream()                         # like the warm-up steps: keep the capture's origin stream idle
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                snap = self._snapshot()
+                loss = self.model(visualize=False, step=self.step_idx, new_epoch=False, idx_shuffle=self.static_idx, **self.static)
+                self.optimizer.zero_grad(set_to_none=True)
+                loss.backward()
+                ref_loss = loss.detach().clone()
+                ref_grads = [None if p.grad is None else p.grad.detach().clone() for p in params]
+                del loss
+                self._restore(snap, optimizer_too=False)      # the eager probe advanced EMA / BN statistics / queue
+                self.optimizer.zero_grad(set_to_none=True)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        self.optimizer.zero_grad(set_to_none=True)
+        try:
+            with torch.cuda.graph(graph):
+                self.static_loss = self._eager(self.static, self.static_idx).detach()
+        except Exception as err:                                # noqa: BLE001
+            if snap is not None:
+                self._restore(snap, optimizer_too=False)        # a capture executes nothing, but host-side lists grew
+            return self._give_up_graph(f"capture failed: {type(err).__name__}: {err}", batch)
+        self.graph = graph
+        self.graph.replay()
+        if self.verify:
+            bad = None
+            if not bool(torch.isfinite(self.static_loss)) or abs(float(self.static_loss) - float(ref_loss)) > 2e-2 * max(1.0, abs(float(ref_loss))):
+                bad = f"loss {float(self.static_loss):.5f} vs eager {float(ref_loss):.5f}"
+            for p, g in zip(params, ref_grads):
+                if bad or g is None or p.grad is None:
+                    continue
+                a, b = p.grad.float(), g.float()
+                den = float(b.norm())
+                err = float((a - b).norm())
+                if not (err == err) or err > 0.2 * den + 1e-6:
+                    bad = f"gradient of a {tuple(p.shape)} parameter: |replay - eager| = {err:.3e}, |eager| = {den:.3e}"
+            if bad:
+                self._restore(snap, optimizer_too=True)
+                return self._give_up_graph("replayed gradients differ from eager: " + bad, batch)
         self.step_idx += 1
         return self.static_loss

@@ -202,3 +202,71 @@ def test_key_forward_graph_equals_eager_key_forward():
             a, b = sa[name].float(), sb[name].float()
             assert (a - b).abs().max().item() <= 1e-2 * b.abs().max().item() + 1e-6, name
     assert int(sa["encoder_k.backbone.bn1.num_batches_tracked"]) == 7
+
+
+def _graph_runner(model, **kw):
+    class A:
+        lr, momentum, weight_decay, optim = 0.03, 0.9, 1e-4, "sgd"
+    opt = make_optimizer(list(model.parameters()), A, DEV, capturable=True, model=model)
+    return TrainStep(model, opt, use_graph=True, warmup_steps=2, **kw)
+
+
+def test_verified_graph_capture_accepts_a_correct_replay():
+    """Graph mode with the start-up check (one eager forward/backward on the same batch and state as the first replay):
+    a correct replay is accepted and training goes on from the graph."""
+    model = small_model(amp_dtype=torch.bfloat16, channels_last=True)
+    model.encoder_q.to(memory_format=torch.channels_last)
+    model.encoder_k.to(memory_format=torch.channels_last)
+    run = _graph_runner(model)
+    torch.manual_seed(5)
+    losses = [float(run(synthetic.make_batch(8, 64, 64, DEV, seed=i))) for i in range(6)]
+    assert run.fallback_reason is None and run.graph is not None and run.use_graph
+    assert all(l == l for l in losses) and int(model.queue_ptr) == 48
+    from cp2_amd.encoder import Conv2d
+    Conv2d.graph_step = False
+
+
+def test_verified_graph_capture_rolls_back_and_continues_eagerly_on_mismatch():
+    """If the first replay's gradients do not match the eager probe, the model / optimizer state is rolled back and the
+    step is redone eagerly: the run then equals an all-eager run (to MIOpen's bf16 run-to-run noise)."""
+    from cp2_amd.encoder import Conv2d
+    out = {}
+    for sabotage in (True, False):
+        model = small_model(amp_dtype=torch.bfloat16, channels_last=True)
+        model.encoder_q.to(memory_format=torch.channels_last)
+        model.encoder_k.to(memory_format=torch.channels_last)
+        if sabotage:
+            run = _graph_runner(model)
+            real_snapshot = run._snapshot
+
+            class Probe(torch.nn.Module):                      # doubles the loss of the eager probe only
+                def __init__(self, inner):
+                    super().__init__()
+                    self.module, self.armed = inner, False
+
+                def forward(self, **kw):
+                    loss = self.module(**kw)
+                    if self.armed and not torch.cuda.is_current_stream_capturing():
+                        self.armed = False
+                        return loss * 2.0
+                    return loss
+            probe = Probe(model)
+            run.model = probe
+
+            def snapshot():
+                probe.armed = True
+                return real_snapshot()
+            run._snapshot = snapshot
+        else:
+            class A:
+                lr, momentum, weight_decay, optim = 0.03, 0.9, 1e-4, "sgd"
+            run = TrainStep(model, make_optimizer(list(model.parameters()), A, DEV, capturable=False, model=model), use_graph=False)
+        torch.manual_seed(5)
+        losses = [float(run(synthetic.make_batch(8, 64, 64, DEV, seed=i))) for i in range(5)]
+        out[sabotage] = (losses, int(model.queue_ptr), run)
+    Conv2d.graph_step = False
+    run = out[True][2]
+    assert run.fallback_reason is not None and "differ from eager" in run.fallback_reason and run.graph is None and not run.use_graph
+    assert out[True][1] == out[False][1] == 40                 # no step was applied twice or lost
+    assert np.allclose(out[True][0][:3], out[False][0][:3], rtol=0, atol=5e-3), (out[True][0], out[False][0])
+    assert np.allclose(out[True][0], out[False][0], rtol=0, atol=8e-2), (out[True][0], out[False][0])
