@@ -169,7 +169,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     loss_val = float(loss)
-    assert loss_val == loss_val or os.environ.get("CP2_BENCH_ALLOW_NAN") == "1", "loss is NaN"
+    assert loss_val == loss_val, "loss is NaN"
 
     ema_ms = sum(ev.elapsed_ms() for ev in ema_events) / len(ema_events)
     n_param_floats = model._flat_q.numel()
