@@ -42,3 +42,37 @@ def test_bn_partial_count_matches_library():
             assert 1 <= g <= 256 and ops._bn_partials(M, C) == g, (M, C)
     assert lib.cp2_bn_num_partials(100, 96) == -3 and lib.cp2_bn_num_partials(100, 8256) == -3
     assert lib.cp2_bn_num_partials(0, 64) == -2
+
+
+def test_split_geometry_functions_are_pure_host_code():
+    """Split counts the callers size their workspaces with (no GPU needed: plain host arithmetic in the library)."""
+    lib = _lib.load()
+    assert lib.cp2_dense_num_splits(8, 4096) == 2          # BASELINE config 4: 256 (sample, tile) items -> 512 workgroups
+    assert lib.cp2_dense_num_splits(32, 196) == 4          # bench shape: at most one 64-pixel tile per split
+    assert lib.cp2_dense_num_splits(8, 1024) == 8
+    assert lib.cp2_dense_num_splits(2, 16) == 1 and lib.cp2_dense_num_splits(64, 4096) == 1
+    assert lib.cp2_dense_num_splits(0, 16) == -2
+    assert lib.cp2_wgrad1x1_num_splits(6272, 2048, 512) == 11 and lib.cp2_wgrad1x1_num_splits(100352, 64, 64) == 628
+    assert lib.cp2_wgrad1x1_num_splits(32, 64, 64) == 1
+    assert lib.cp2_wgrad1x1_num_splits(6272, 96, 64) == -3 and lib.cp2_wgrad1x1_num_splits(0, 64, 64) == -2
+
+
+def test_sgd_flat_plan_covers_every_slot_once():
+    """Block table of cp2_sgd_flat: blocks never straddle tensors, cover each tensor's elements exactly once, and
+    address the flat buffer at the slot offsets MODEL.flatten_parameters() hands out (256-byte aligned slots)."""
+    import numpy as np
+    import torch
+    numels = [64, 9408, 1, 513, 36864, 7]
+    offs, total = [], 0
+    for n in numels:
+        offs.append(total)
+        total += (n + 63) // 64 * 64
+    plan = ops.SgdFlatPlan(offs, numels, torch.device("cpu"))
+    tab = plan.blk_tab.numpy()
+    first = np.ctypeslib.as_array(plan.first)
+    assert plan.ntensors == len(numels) and first[0] == 0 and first[-1] == len(tab)
+    for t, (off, n) in enumerate(zip(offs, numels)):
+        rows = tab[first[t]:first[t + 1]]
+        assert (rows[:, 0] == t).all()
+        assert (rows[:, 3] > 0).all() and (rows[:, 3] <= ops.SGD_BLOCK_FLOATS).all() and rows[:, 3].sum() == n
+        assert (rows[:, 1] - off == rows[:, 2]).all() and (rows[:, 2] == np.arange(len(rows)) * ops.SGD_BLOCK_FLOATS).all()
