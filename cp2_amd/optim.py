@@ -13,6 +13,12 @@ import torch
 from . import ops
 
 
+def _same_element_order(g: torch.Tensor, p: torch.Tensor) -> bool:
+    """Strides agree on every dimension that has more than one element (a [co, ci, 1, 1] weight is the same memory in
+    'contiguous' and 'channels-last' strides)."""
+    return all(sg == sp for sg, sp, n in zip(g.stride(), p.stride(), p.shape) if n > 1)
+
+
 class FlatSGD(torch.optim.Optimizer):
     def __init__(self, model, lr, momentum: float = 0.0, weight_decay: float = 0.0, dampening: float = 0.0,
                  nesterov: bool = False):
@@ -72,7 +78,7 @@ class FlatSGD(torch.optim.Optimizer):
                 continue
             if g.dtype != torch.float32 or g.is_sparse:
                 raise TypeError("FlatSGD: fp32 dense gradients only")
-            if g.stride() != p.stride():        # element order of the slot = the parameter's own dense layout
+            if g.stride() != p.stride() and not _same_element_order(g, p):   # slot order = the parameter's own dense layout
                 g = torch.empty_strided(p.shape, p.stride(), dtype=g.dtype, device=g.device).copy_(g)
                 keep.append(g)
             grads[i] = g.data_ptr()
