@@ -86,10 +86,16 @@ class _ShadowWeightFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, weight, shadow):
+        ctx.wshape, ctx.wstride = weight.shape, weight.stride()
         return shadow.view_as(shadow)
 
     @staticmethod
     def backward(ctx, g):
+        # MIOpen returns some weight gradients NCHW-dense although the weight is channels-last: cast and re-lay in ONE
+        # kernel, so that neither the optimizer (slot order = the parameter's layout) nor DDP (bucket views follow the
+        # parameter's strides) has to copy the gradient again
+        if any(sg != sw for sg, sw, n in zip(g.stride(), ctx.wstride, ctx.wshape) if n > 1):
+            return torch.empty_strided(ctx.wshape, ctx.wstride, dtype=torch.float32, device=g.device).copy_(g), None
         return g.to(torch.float32), None
 
 
