@@ -48,6 +48,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--gemm-1x1", default="on", choices=["on", "off"],
                    help="1x1 stride-1 convolutions: hipBLASLt GEMM for forward / data gradient where faster (A/B)")
+    p.add_argument("--cpp-nodes", default="on", choices=["on", "off"],
+                   help="C++ autograd nodes for the weight images / 1x1 convolutions (off: the Python nodes) (A/B)")
     p.add_argument("--flat-sgd", default="on", choices=["on", "off"],
                    help="optimizer step as one HIP launch on the flat parameter buffer (off: torch.optim.SGD) (A/B)")
     p.add_argument("--fused-bn", default="on", choices=["on", "off"], help="encoder fast path: fused BN(+add)(+ReLU) kernels (A/B)")
@@ -96,6 +98,7 @@ def main():
     FusedBatchNorm2d.fused = args.fused_bn == "on"
     from cp2_amd.encoder import Conv2d
     Conv2d.gemm_1x1 = args.gemm_1x1 == "on"
+    Conv2d.cpp_nodes = args.cpp_nodes == "on"
     from cp2_amd.config import Config
     from cp2_amd.engine import TrainStep
     from cp2_amd.main import make_optimizer

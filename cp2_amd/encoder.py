@@ -26,6 +26,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+from . import _cext  # noqa: E402
 from . import ops as _bn_ops  # noqa: E402  (ctypes front end; only touched on the GPU fast path)
 
 
@@ -162,10 +163,12 @@ class Conv2d(nn.Conv2d):
     shadow_weight = None
     gemm_1x1 = True          # class-wide switch (A/B)
     graph_step = False       # set by engine.TrainStep(use_graph=True): warm-up steps must take the path the capture takes
+    cpp_nodes = True         # autograd nodes from the C++ extension when it is built (A/B: False = the Python nodes)
 
     def forward(self, x):
         w = self.shadow_weight
         if w is not None and x.dtype == torch.bfloat16:
+            ext = _cext.load() if Conv2d.cpp_nodes else None
             if (Conv2d.gemm_1x1 and self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0)
                     and self.groups == 1 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
                 m, ci, co = x.shape[0] * x.shape[2] * x.shape[3], self.in_channels, self.out_channels
@@ -173,12 +176,15 @@ class Conv2d(nn.Conv2d):
                 if not (torch.is_grad_enabled() and (self.weight.requires_grad or x.requires_grad)):
                     if mm_fwd:                      # gradient-free forward (key encoder): no autograd node needed
                         return _Conv1x1Fn.forward(_NoCtx, x, None, w, self.bias, True, False)
+                elif ext is not None:
+                    # C++ node: GEMM forward / data gradient where faster, weight gradient by cp2_wgrad1x1 (fp32)
+                    return ext.conv1x1(x, self.weight, w, self.bias, mm_fwd, ci >= 128, _Conv1x1Fn.hip_wgrad)
                 elif Conv2d.graph_step or torch.cuda.is_current_stream_capturing():
-                    # with autograd the Python-side Function costs ~0.1 ms of host time per layer and step: worth it
-                    # only when the step is being captured into a hipGraph (host time is then paid once)
+                    # the Python node costs ~0.1 ms of host time per layer and step: worth it only when the step is
+                    # being captured into a hipGraph (host time is then paid once)
                     return _Conv1x1Fn.apply(x, self.weight, w, self.bias, mm_fwd, ci >= 128)
             if self.weight.requires_grad and torch.is_grad_enabled():
-                w = _ShadowWeightFn.apply(self.weight, w)
+                w = ext.shadow_weight(self.weight, w) if ext is not None else _ShadowWeightFn.apply(self.weight, w)
             b = self.bias.to(torch.bfloat16) if self.bias is not None else None
             return self._conv_forward(x, w, b)
         return super().forward(x)

@@ -76,3 +76,12 @@ def test_sgd_flat_plan_covers_every_slot_once():
         assert (rows[:, 0] == t).all()
         assert (rows[:, 3] > 0).all() and (rows[:, 3] <= ops.SGD_BLOCK_FLOATS).all() and rows[:, 3].sum() == n
         assert (rows[:, 1] - off == rows[:, 2]).all() and (rows[:, 2] == np.arange(len(rows)) * ops.SGD_BLOCK_FLOATS).all()
+
+
+def test_cpp_autograd_nodes_are_built_and_importable():
+    """cp2_amd/_autograd_ext (host-side C++ autograd nodes) is part of the build: it must import and be wired to the
+    library's weight-gradient entry points."""
+    from cp2_amd import _cext
+    ext = _cext.load()
+    assert ext is not None, "run `python -c 'import __graft_entry__ as g; g.build()'` first"
+    assert all(hasattr(ext, n) for n in ("conv1x1", "shadow_weight", "set_wgrad"))

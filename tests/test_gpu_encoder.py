@@ -83,3 +83,45 @@ def test_wgrad1x1_matches_fp32_matmul(N, H, W, co, ci):
     err = (dw.view(co, ci).double() - ref).abs().max().item()
     assert err <= 2e-5 * ref.abs().max().item() + 1e-6, err
     assert torch.equal(dw, ops.wgrad1x1(dy, x))                 # run-to-run identical
+
+
+@pytest.mark.parametrize("N,HW,ci,co,bias", [(8, 14, 512, 2048, False), (4, 28, 512, 128, True), (2, 56, 64, 256, False), (3, 7, 192, 320, True)])
+@pytest.mark.parametrize("mm_fwd,mm_dgrad", [(True, True), (False, False)])
+def test_cpp_conv1x1_node_equals_python_node(N, HW, ci, co, bias, mm_fwd, mm_dgrad):
+    """The C++ autograd node launches the same kernels as the Python node: identical outputs and gradients."""
+    from cp2_amd import _cext
+    ext = _cext.load()
+    assert ext is not None
+    torch.manual_seed(ci * 3 + co)
+    x = torch.randn(N, ci, HW, HW, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(co, ci, 1, 1, device=DEV) * ci ** -0.5).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(co, device=DEV) if bias else None
+    up = torch.randn(N, co, HW, HW, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    res = []
+    for use_cpp in (True, False):
+        xa, wa = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        ba = b.clone().requires_grad_(True) if bias else None
+        sh = wa.detach().to(torch.bfloat16)
+        y = ext.conv1x1(xa, wa, sh, ba, mm_fwd, mm_dgrad, True) if use_cpp else _Conv1x1Fn.apply(xa, wa, sh, ba, mm_fwd, mm_dgrad)
+        y.backward(up)
+        res.append((y.detach(), xa.grad, wa.grad, ba.grad if bias else None))
+    for a, c, name in zip(res[0], res[1], ("y", "dx", "dw", "db")):
+        if a is None:
+            continue
+        assert a.dtype == c.dtype and a.shape == c.shape, name
+        if name == "dw":
+            assert torch.equal(a, c), name                      # both from cp2_wgrad1x1 (deterministic)
+        else:
+            close(a, c, 2e-2, name)                             # MIOpen / hipBLASLt may differ run to run in bf16
+
+
+def test_cpp_shadow_weight_node():
+    from cp2_amd import _cext
+    ext = _cext.load()
+    w = torch.randn(64, 32, 3, 3, device=DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    sh = w.detach().to(torch.bfloat16)
+    out = ext.shadow_weight(w, sh)
+    assert out.data_ptr() == sh.data_ptr() and out.dtype == torch.bfloat16 and out.requires_grad
+    g = torch.randn(64, 32, 3, 3, device=DEV).to(torch.bfloat16)            # NCHW-dense gradient for a channels-last weight
+    out.backward(g)
+    assert w.grad.dtype == torch.float32 and w.grad.stride() == w.stride() and torch.equal(w.grad, g.float())
