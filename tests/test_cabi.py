@@ -52,7 +52,7 @@ def test_split_geometry_functions_are_pure_host_code():
     assert lib.cp2_dense_num_splits(8, 1024) == 8
     assert lib.cp2_dense_num_splits(2, 16) == 1 and lib.cp2_dense_num_splits(64, 4096) == 1
     assert lib.cp2_dense_num_splits(0, 16) == -2
-    assert lib.cp2_wgrad1x1_num_splits(6272, 2048, 512) == 11 and lib.cp2_wgrad1x1_num_splits(100352, 64, 64) == 628
+    assert lib.cp2_wgrad1x1_num_splits(6272, 2048, 512) == 8 and lib.cp2_wgrad1x1_num_splits(100352, 64, 64) == 448
     assert lib.cp2_wgrad1x1_num_splits(32, 64, 64) == 1
     assert lib.cp2_wgrad1x1_num_splits(6272, 96, 64) == -3 and lib.cp2_wgrad1x1_num_splits(0, 64, 64) == -2
 
