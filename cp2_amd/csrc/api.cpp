@@ -2,7 +2,7 @@
 #include <hip/hip_runtime.h>
 #include "../../include/cp2hip.h"
 
-extern "C" __attribute__((visibility("default"))) int cp2_version(void) { return 100; }
+extern "C" __attribute__((visibility("default"))) int cp2_version(void) { return 200; }   // 0.2.0: split workspaces of the dense kernels, cp2_sgd_flat, cp2_wgrad1x1
 
 extern "C" __attribute__((visibility("default"))) const char* cp2_error_string(int code) {
     switch (code) {
