@@ -33,16 +33,26 @@ __device__ __forceinline__ wg_bf16x8 wg_frag(const unsigned short* tile, int ks,
     return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8).  All output tiles of one m-split read the same rows
+// of dY and X, so a split's tiles should share one XCD's L2: linear id -> item such that each XCD owns a contiguous run
+// of (split, tile) items, split-major (bijective for any grid size; MI355X guide T1).  Without it every XCD pulls every
+// row range through its own L2 (8x the fill traffic on the wide layers).
+__device__ __forceinline__ int wg_xcd_item(int id, int n_items) {
+    const int q = n_items / 8, rem = n_items % 8, xcd = id % 8, j = id / 8;
+    return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + j;
+}
+
 template <int F>   // F x F MFMA tiles per wave; workgroup tile = 64F x 64F channels, 4 waves as 2 x 2
 __global__ __launch_bounds__(256) void wgrad1x1_kernel(const unsigned short* __restrict__ dy,
                                                        const unsigned short* __restrict__ x, float* __restrict__ part,
-                                                       int M, int CO, int CI, int rows_per_split, int tiles_ci) {
+                                                       int M, int CO, int CI, int rows_per_split, int tiles_ci, int tiles) {
     constexpr int T = 64 * F, PITCH = T + 8, CPR = T / 8;            // channels per tile edge, LDS row pitch, 16-B chunks per row
     __shared__ __attribute__((aligned(16))) unsigned short lds[2][2][WG_KM * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wy = wid >> 1, wx = wid & 1;
     const int r = lane & 31, h = lane >> 5;
-    const int co0 = (blockIdx.x / tiles_ci) * T, ci0 = (blockIdx.x % tiles_ci) * T;
-    const int m_begin = blockIdx.y * rows_per_split, m_end = min(M, m_begin + rows_per_split);
+    const int item = wg_xcd_item(blockIdx.x, gridDim.x), split = item / tiles, tile = item % tiles;
+    const int co0 = (tile / tiles_ci) * T, ci0 = (tile % tiles_ci) * T;
+    const int m_begin = split * rows_per_split, m_end = min(M, m_begin + rows_per_split);
     wg_f32x16 acc[F][F];
 #pragma unroll
     for (int a = 0; a < F; ++a)
@@ -88,7 +98,7 @@ __global__ __launch_bounds__(256) void wgrad1x1_kernel(const unsigned short* __r
         __syncthreads();
         buf ^= 1;
     }
-    float* out = part + (int64_t)blockIdx.y * CO * CI;
+    float* out = part + (int64_t)split * CO * CI;
 #pragma unroll
     for (int a = 0; a < F; ++a)
 #pragma unroll
@@ -168,10 +178,11 @@ CP2_API int cp2_wgrad1x1(const void* dy, const void* x, float* dw, float* part, 
     const unsigned short* xx = static_cast<const unsigned short*>(x);
     hipStream_t s = cp2_stream(stream);
     const int T = 64 * F, tiles_ci = CI / T;
-    const dim3 grid((CO / T) * tiles_ci, S);
+    const int tiles = (CO / T) * tiles_ci;
+    const dim3 grid(tiles * S);
     float* out = S == 1 ? dw : part;
-    if (F == 2) hipLaunchKernelGGL(wgrad1x1_kernel<2>, grid, dim3(256), 0, s, d, xx, out, M, CO, CI, rows, tiles_ci);
-    else hipLaunchKernelGGL(wgrad1x1_kernel<1>, grid, dim3(256), 0, s, d, xx, out, M, CO, CI, rows, tiles_ci);
+    if (F == 2) hipLaunchKernelGGL(wgrad1x1_kernel<2>, grid, dim3(256), 0, s, d, xx, out, M, CO, CI, rows, tiles_ci, tiles);
+    else hipLaunchKernelGGL(wgrad1x1_kernel<1>, grid, dim3(256), 0, s, d, xx, out, M, CO, CI, rows, tiles_ci, tiles);
     int rc2 = cp2_launch_status();
     if (rc2 || S == 1) return rc2;
     const int64_t n4 = (int64_t)CO * CI / 4;
