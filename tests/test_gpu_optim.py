@@ -133,6 +133,9 @@ def test_training_step_with_flat_sgd_matches_torch_sgd_step():
         run = TrainStep(m, opt, use_graph=False)
         torch.manual_seed(7)
         losses.append([float(run(synthetic.make_batch(8, 64, 64, DEV, seed=i))) for i in range(4)])
-    # same maths; MIOpen's bf16 split-K kernels (atomics, forward and weight gradient) are not run-to-run reproducible
-    assert abs(losses[0][0] - losses[1][0]) <= 1e-3 and abs(losses[0][1] - losses[1][1]) <= 3e-3, losses
-    assert all(abs(a - b) < 5e-2 for a, b in zip(*losses)), losses
+    # same maths, different kernels: the FlatSGD model reads bf16 weight images and sends its 1x1 layers through
+    # hipBLASLt / cp2_wgrad1x1, the torch-SGD model goes through autocast + MIOpen (whose bf16 split-K solvers are not
+    # even run-to-run reproducible); the optimizer itself is compared bit for bit above.  Early steps close, later
+    # steps within the drift two identical eager runs show.
+    assert abs(losses[0][0] - losses[1][0]) <= 2e-3 and abs(losses[0][1] - losses[1][1]) <= 2e-2, losses
+    assert all(abs(a - b) < 1.5e-1 for a, b in zip(*losses)), losses
