@@ -90,7 +90,10 @@ struct Conv1x1Fn : public torch::autograd::Function<Conv1x1Fn> {
             const int M = (int)(N * H * W);
             const int S = g_wgrad_splits(M, (int)co, (int)C);
             TORCH_CHECK(S >= 1, "cp2_wgrad1x1_num_splits failed: ", S);
-            dw = at::empty({co, C, 1, 1}, x.options().dtype(at::kFloat));
+            // the master's own strides (for a [co, ci, 1, 1] weight every dense layout is the same memory): the gradient
+            // then matches DDP's bucket views and the optimizer's slot order without another copy
+            dw = at::empty_strided(ctx->saved_data["wshape"].toIntVector(), ctx->saved_data["wstride"].toIntVector(),
+                                   x.options().dtype(at::kFloat));
             at::Tensor part = S > 1 ? at::empty({(int64_t)S * co * C}, dw.options()) : dw;
             const int rc = g_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr<float>(), part.data_ptr<float>(), M, (int)co, (int)C,
                                    c10::hip::getCurrentHIPStream().stream());

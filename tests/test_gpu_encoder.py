@@ -110,6 +110,7 @@ def test_cpp_conv1x1_node_equals_python_node(N, HW, ci, co, bias, mm_fwd, mm_dgr
             continue
         assert a.dtype == c.dtype and a.shape == c.shape, name
         if name == "dw":
+            assert a.stride() == w.stride()                     # C++ node: the master weight's own strides
             assert torch.equal(a, c), name                      # both from cp2_wgrad1x1 (deterministic)
         else:
             close(a, c, 2e-2, name)                             # MIOpen / hipBLASLt may differ run to run in bf16
