@@ -215,7 +215,8 @@ def main():
                                                steps=args.cpu_steps, warmup=1)
         out["cpu_baseline"] = {"value": round(ips, 3), "unit": "images/sec", "cores": threads, "kind": "port",
                                "sample": f"{args.cpu_steps} steps of {args.cpu_batch} images ({hw}x{hw}, queue {args.queue}, "
-                                         f"same model) after 1 warm-up step, fp32, {secs:.1f} s"}
+                                         f"same model) after 1 warm-up step, fp32, {secs:.1f} s",
+                               "split_ms_per_step": time_cpu_baseline.last_split_ms}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

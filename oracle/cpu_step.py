@@ -30,25 +30,39 @@ class CpuCP2Step:
         self.m, self.tg, self.tl, self.lmbd, self.os = m, temp_global, temp_local, lmbd_dense, output_stride
         self.opt = torch.optim.SGD([p for p in self.enc_q.parameters() if p.requires_grad], lr, momentum=momentum,
                                    weight_decay=weight_decay)
+        self.split = {}
 
     def step(self, batch):
+        """One step; wall time per phase is accumulated in self.split (seconds): composition, query forward, EMA,
+        key forward (+ shuffle), loss section incl. statistics, enqueue, backward + SGD."""
+        tick = time.perf_counter
+        t = [tick()]
         img_a, _ = O.compose_mask(batch["img_a"], batch["bg0"])
         img_b, _ = O.compose_mask(batch["img_b"], batch["bg1"])
+        t.append(tick())
         q = self.enc_q(img_a)
+        t.append(tick())
         with torch.no_grad():
             new = O.momentum_update([p.data for p in self.enc_k.parameters()], [p.data for p in self.enc_q.parameters()], self.m)
             for p, v in zip(self.enc_k.parameters(), new):
                 p.data = v
+            t.append(tick())
             perm = torch.randperm(img_b.shape[0])
             k = O.unshuffle_take(self.enc_k(O.shuffle_take(img_b, perm, 0, 1)), perm, 0, 1)
+        t.append(tick())
         out = O.cp2_loss_section(q, k, batch["bg0"], batch["bg1"], batch["pixel_ids_a"], batch["pixel_ids_b"],
                                  batch["region_ids_a"], batch["region_ids_b"], self.queue, output_stride=self.os,
                                  temp_global=self.tg, temp_local=self.tl, lmbd_dense=self.lmbd, with_stats=True)
+        t.append(tick())
         self.queue, self.ptr = O.dequeue_and_enqueue(self.queue, self.ptr, out["k_pos"].detach())
+        t.append(tick())
         self.opt.zero_grad()
         out["loss"].backward()
         self.opt.step()
-        return float(out["loss"])
+        t.append(tick())
+        for name, a, b in zip(("compose", "query_fwd", "ema", "key_fwd", "loss_section", "enqueue", "backward_sgd"), t, t[1:]):
+            self.split[name] = self.split.get(name, 0.0) + (b - a)
+        return float(out["loss"].detach())
 
 
 def time_cpu_baseline(cfg, make_batch, b, h, w, K, steps=2, warmup=1, threads=None):
@@ -59,8 +73,13 @@ def time_cpu_baseline(cfg, make_batch, b, h, w, K, steps=2, warmup=1, threads=No
     batches = [{k: v.cpu() for k, v in make_batch(b, h, w, "cpu", seed=100 + i).items()} for i in range(warmup + steps)]
     for i in range(warmup):
         runner.step(batches[i])
+    runner.split = {}
     t0 = time.perf_counter()
     for i in range(warmup, warmup + steps):
         runner.step(batches[i])
     dt = time.perf_counter() - t0
+    time_cpu_baseline.last_split_ms = {k: round(1e3 * v / steps, 1) for k, v in runner.split.items()}   # per step
     return b * steps / dt, torch.get_num_threads(), dt
+
+
+time_cpu_baseline.last_split_ms = {}
