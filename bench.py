@@ -64,14 +64,22 @@ def parse():
 
 
 def count_flops_per_image(model, batch):
-    """FLOPs of one step (q forward+backward, k forward, loss GEMMs excluded) via torch's flop counter."""
+    """FLOPs of one step (q forward+backward, k forward, loss GEMMs excluded) via torch's flop counter.  The counter only
+    sees ATen operators, so the pass runs with every convolution on the ATen path (the product path sends the 1x1
+    weight gradients through cp2_wgrad1x1, which it would not count)."""
     from torch.utils.flop_counter import FlopCounterMode
-    with FlopCounterMode(display=False) as fc:
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            y = model.encoder_q(batch["img_a"])
-            with torch.no_grad():
-                model.encoder_k(batch["img_b"])
-        y.float().mean().backward()
+    from cp2_amd.encoder import Conv2d
+    saved = (Conv2d.cpp_nodes, Conv2d.gemm_1x1)
+    Conv2d.cpp_nodes, Conv2d.gemm_1x1 = False, False
+    try:
+        with FlopCounterMode(display=False) as fc:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = model.encoder_q(batch["img_a"])
+                with torch.no_grad():
+                    model.encoder_k(batch["img_b"])
+            y.float().mean().backward()
+    finally:
+        Conv2d.cpp_nodes, Conv2d.gemm_1x1 = saved
     model.encoder_q.zero_grad(set_to_none=True)
     return fc.get_total_flops() / batch["img_a"].shape[0]
 
