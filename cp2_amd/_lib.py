@@ -25,7 +25,7 @@ SIGNATURES = {
     "cp2_ema_flat_timed": [_P, _P, c_int64, c_float, c_float, _P, _P, _P],
     "cp2_ema_flat_shadow": [_P, _P, _P, c_int64, c_float, c_float, _P, _P, _P],
     "cp2_ema_multi": [_P, _P, _P, _P, _P, c_int, c_float, c_float, _P],
-    "cp2_enqueue": [_P, _P, _P, c_int, c_int, c_int, _P],
+    "cp2_enqueue": [_P, _P, _P, _P, c_int, c_int, c_int, _P],
     "cp2_feat_normalize_pool": [_P, c_int64, c_int64, c_int64, _P, _P, _P, _P, c_int, c_int, c_int, _P],
     "cp2_pool_finalize": [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
     "cp2_pool_bwd": [_P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, _P],

@@ -1,15 +1,15 @@
 // a13: queue enqueue with wrap-around -- reference builder.py:569-587.
 // keys [n,C] (row = key) are transposed into columns (ptr+i) % K of queue [C,K].
 // 32x32 tiles go through LDS so both the read (along C) and the write (along K)
-// are coalesced.  The pointer lives on the device: it is read by the scatter
-// kernel and advanced by a one-thread kernel that follows it on the same stream,
-// so there is no host synchronisation (the reference does int(queue_ptr)).
+// are coalesced.  The pointer lives on the device (the reference does int(queue_ptr), a host
+// synchronisation): every workgroup reads it before it stores anything, and the workgroup that
+// draws the last ticket of a caller-owned counter advances it, so the whole enqueue is ONE launch.
 #include "common.hpp"
 
 __global__ __launch_bounds__(256) void enqueue_scatter_kernel(float* __restrict__ queue,
                                                               const float* __restrict__ keys,
-                                                              const int64_t* __restrict__ ptr, int n, int C,
-                                                              int K) {
+                                                              int64_t* __restrict__ ptr, int32_t* __restrict__ ticket,
+                                                              int n, int C, int K) {
     __shared__ float tile[32][33];
     const int i0 = blockIdx.x * 32;  // key tile
     const int c0 = blockIdx.y * 32;  // channel tile
@@ -26,18 +26,22 @@ __global__ __launch_bounds__(256) void enqueue_scatter_kernel(float* __restrict_
         const int c = c0 + ty + 8 * r, i = i0 + tx;
         if (i < n && c < C) queue[(int64_t)c * K + (p + i) % K] = tile[tx][ty + 8 * r];
     }
+    // every thread of this workgroup holds p in a register by now (its stores were addressed with it)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int total = gridDim.x * gridDim.y;
+        if (atomicAdd(ticket, 1) == total - 1) {     // all other workgroups have read the pointer: advance it
+            *ptr = (p + n) % K;
+            *ticket = 0;                             // ready for the next launch (stream order makes it visible)
+        }
+    }
 }
 
-__global__ void enqueue_advance_kernel(int64_t* ptr, int n, int K) { *ptr = (*ptr + n) % K; }
-
-CP2_API int cp2_enqueue(float* queue, const float* keys, int64_t* ptr, int n, int C, int K, void* stream) {
-    if (!queue || !keys || !ptr) return CP2_ERR_NULL;
+CP2_API int cp2_enqueue(float* queue, const float* keys, int64_t* ptr, int32_t* ticket, int n, int C, int K, void* stream) {
+    if (!queue || !keys || !ptr || !ticket) return CP2_ERR_NULL;
     if (n <= 0 || C <= 0 || K <= 0) return CP2_ERR_SHAPE;
     if (n > K) return CP2_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(enqueue_scatter_kernel, dim3(cp2_cdiv(n, 32), cp2_cdiv(C, 32)), dim3(256), 0,
-                       cp2_stream(stream), queue, keys, ptr, n, C, K);
-    int rc = cp2_launch_status();
-    if (rc) return rc;
-    hipLaunchKernelGGL(enqueue_advance_kernel, dim3(1), dim3(1), 0, cp2_stream(stream), ptr, n, K);
+                       cp2_stream(stream), queue, keys, ptr, ticket, n, C, K);
     return cp2_launch_status();
 }

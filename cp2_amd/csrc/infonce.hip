@@ -19,16 +19,7 @@
 //   dense_fwd    owners = key pixels y, others = query pixels x of the same sample
 //                builder.py:1289-1292,1392,1431-1437 (column-wise log-softmax, dim=1)
 //   dense_bwd    owners = query pixels x, others = key pixels y: d loss / d q_dense
-#include "common.hpp"
-#include <math.h>
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int CH = 128;  // feature channels (MODEL dim, main.py:404-412)
-
-__device__ __forceinline__ int rho(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
-__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
+#include "infonce_common.hpp"
 
 // LDS tile T[c][j], j < KT, row pitch KT+1 floats (odd pitch: both the row read of
 // product 1 and the column read of product 2 are bank-conflict free).  The fill is split
@@ -126,14 +117,6 @@ __device__ __forceinline__ void product2(const float* __restrict__ T, int kk, co
 // ===========================================================================
 // rows-vs-queue InfoNCE, forward with fused gradient accumulation
 // ===========================================================================
-struct RowKeyArgs {
-    const float* rows; int RP; int64_t r_sn, r_sx, r_sc; int R;  // row r -> (n=r/RP, x=r%RP), element (c,r) at n*r_sn + x*r_sx + c*r_sc
-    const float* keys; int K;                                     // [CH][K]
-    const float* extras; int NE; float inv_t;                     // raw extra logits [R][NE], column 0 = positive
-    int keys_per_split;
-    float* part_m; float* part_s; int* part_cnt; float* part_U;   // [S][R], [S][R], [S][R], [S][CH][R]
-    float* lnegT;                                                  // optional raw logits, key-major [K][R]
-};
 
 template <int WR, int WK, bool WITH_U>
 __global__ __launch_bounds__(256, WK == 1 ? 2 : 1) void rowkey_fwd_kernel(RowKeyArgs a) {
@@ -667,6 +650,13 @@ __global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ x, 
     if (threadIdx.x == 0) out[0] = (red[0] + red[1] + red[2] + red[3]) / (float)n;
 }
 
+// One 32-row tile and 16-byte addressable key rows: the barrier-free LDS-DMA kernel of rowkey_small.hip
+static bool rowkey_use_small(int R, int K) { return R <= 32 && K % 4 == 0 && K <= (1 << 21); }
+// ... which also needs channel-contiguous, 16-byte aligned rows (else the register-staged kernels run with the same split count)
+static bool rowkey_small_rows_ok(const float* rows, int64_t r_sn, int64_t r_sx, int64_t r_sc, const float* keys) {
+    return r_sc == 1 && r_sn % 4 == 0 && r_sx % 4 == 0 && cp2_aligned16(rows) && cp2_aligned16(keys);
+}
+
 static int rowkey_shape(int R, int* WR, int* WK) {
     if (R <= 32) { *WR = 1; *WK = 4; }
     else if (R <= 64) { *WR = 2; *WK = 2; }
@@ -680,6 +670,7 @@ CP2_API int cp2_rowkey_num_splits(int R, int K) {
     // took as long as 1024 would).  Pick the split count whose last wave is fullest, preferring 2-3 waves so that
     // uneven workgroups still balance, with at least 8 LDS tiles of keys per split (2 when there is one row block).
     if (R <= 0 || K <= 0) return CP2_ERR_SHAPE;
+    if (rowkey_use_small(R, K)) return rowkey_small_num_splits(K, nullptr);
     int WR, WK;
     rowkey_shape(R, &WR, &WK);
     const int KT = 32 * WK * (WK == 1 ? 2 : 1);
@@ -710,6 +701,11 @@ CP2_API int cp2_rowkey_infonce_fwd(const float* rows, int RP, int64_t r_sn, int6
     if (NE > 0 && !extras) return CP2_ERR_NULL;
     if (R <= 0 || K <= 0 || RP <= 0 || nsplit <= 0 || NE < 0 || NE > 4 || !(temperature > 0.f)) return CP2_ERR_SHAPE;
     if (C != CH) return CP2_ERR_UNSUPPORTED;
+    if (rowkey_use_small(R, K) && rowkey_small_rows_ok(rows, r_sn, r_sx, r_sc, keys)) {
+        RowKeyArgs sa{rows, RP, r_sn, r_sx, r_sc, R, keys, K, extras, NE, 1.0f / temperature, 0,
+                      part_m, part_s, part_cnt, part_U, lnegT};
+        return rowkey_small_launch(sa, nsplit, part_U != nullptr, cp2_stream(stream));
+    }
     int WR, WK;
     rowkey_shape(R, &WR, &WK);
     const int KT = 32 * WK * (WK == 1 ? 2 : 1);

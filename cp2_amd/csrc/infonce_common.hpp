@@ -1,0 +1,26 @@
+// Shared pieces of the contrastive-logit kernels (infonce.hip, rowkey_small.hip, dense_stats.hip).
+#pragma once
+#include "common.hpp"
+#include <math.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int CH = 128;  // feature channels (MODEL dim, main.py:404-412)
+
+// v_mfma_f32_32x32x2_f32 accumulator: register `reg` of lane half h holds row rho(reg, h) of the 32x32 tile
+__device__ __forceinline__ int rho(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+struct RowKeyArgs {
+    const float* rows; int RP; int64_t r_sn, r_sx, r_sc; int R;  // row r -> (n=r/RP, x=r%RP), element (c,r) at n*r_sn + x*r_sx + c*r_sc
+    const float* keys; int K;                                     // [CH][K]
+    const float* extras; int NE; float inv_t;                     // raw extra logits [R][NE], column 0 = positive
+    int keys_per_split;
+    float* part_m; float* part_s; int* part_cnt; float* part_U;   // [S][R], [S][R], [S][R], [S][CH][R]
+    float* lnegT;                                                  // optional raw logits, key-major [K][R]
+};
+
+// Small-R form (R <= 32 rows, K % 4 == 0, 16-byte aligned keys): rowkey_small.hip
+int rowkey_small_num_splits(int K, int* tiles_per_wg);
+int rowkey_small_launch(const RowKeyArgs& a, int nsplit, bool with_u, hipStream_t stream);

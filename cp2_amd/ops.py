@@ -236,8 +236,19 @@ class EmaMultiPlan:
 
 
 # ---------------------------------------------------------------- a13
+_ENQUEUE_TICKETS = {}
+
+
+def _enqueue_ticket(device) -> torch.Tensor:
+    """One zeroed int32 per device: the ticket counter of cp2_enqueue (the kernel leaves it zero)."""
+    key = str(device)
+    if key not in _ENQUEUE_TICKETS:
+        _ENQUEUE_TICKETS[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _ENQUEUE_TICKETS[key]
+
+
 def enqueue(queue: torch.Tensor, keys: torch.Tensor, ptr: torch.Tensor) -> None:
-    """In place: queue[:, (ptr+i) % K] = keys[i]; ptr = (ptr + n) % K, all on the device
+    """In place: queue[:, (ptr+i) % K] = keys[i]; ptr = (ptr + n) % K, all on the device, one launch
     (reference builder.py:569-587; keys are already gathered over ranks)."""
     lib = _lib.load()
     C, K = queue.shape
@@ -247,7 +258,7 @@ def enqueue(queue: torch.Tensor, keys: torch.Tensor, ptr: torch.Tensor) -> None:
     if ptr.numel() != 1:
         raise ValueError("enqueue: ptr must hold one int64")
     rc = lib.cp2_enqueue(_dev(queue, "queue", torch.float32), _dev(keys, "keys", torch.float32),
-                         _dev(ptr, "queue_ptr", torch.int64), n, C, K, _stream())
+                         _dev(ptr, "queue_ptr", torch.int64), _enqueue_ticket(queue.device).data_ptr(), n, C, K, _stream())
     _lib.check(rc, "cp2_enqueue")
 
 

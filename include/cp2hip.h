@@ -89,8 +89,10 @@ int cp2_ema_multi(float* const* k_ptrs, const float* const* q_ptrs, const int32_
 /* ---- a13: queue enqueue with wrap-around ------------------ builder.py:569-587
  * queue[c, (ptr+i) % K] = keys[i, c] for i < n, then *ptr = (ptr + n) % K.
  * queue: [C,K] f32; keys: [n,C] f32 (already gathered over ranks); ptr: device int64[1].
- * The pointer is read and advanced on the device: no host synchronisation.  n <= K. */
-int cp2_enqueue(float* queue, const float* keys, int64_t* ptr, int n, int C, int K, void* stream);
+ * The pointer is read and advanced on the device: no host synchronisation.  n <= K.
+ * ticket: device int32[1] owned by the caller, zero before the first call (the kernel leaves it zero): the
+ * workgroup that finishes last advances the pointer, so the enqueue is a single launch. */
+int cp2_enqueue(float* queue, const float* keys, int64_t* ptr, int32_t* ticket, int n, int C, int K, void* stream);
 
 /* ---- a7: per-pixel L2 normalise + masked pooling ---------- builder.py:1261-1268,1279-1285
  * feat: encoder output addressed as feat[n*stride_n + c*stride_c + x*stride_p] (NCHW or channels-last),

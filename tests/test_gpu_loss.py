@@ -126,6 +126,9 @@ def _oracle_loss(q, k, ma, mb, queue, tg, tl, lmbd, inc_bg):
     (70, (3, 3), 4096, True, torch.contiguous_format),     # > 64 rows
     (2, (32, 32), 2048, False, torch.channels_last),       # P = 1024 (config 4 at OS16)
     (1, (12, 11), 64, False, torch.contiguous_format),     # P = 132: partial 32-tile and partial 64-tile
+    (20, (2, 2), 1001, True, torch.contiguous_format),     # K % 4 != 0: the register-staged one-row-tile kernel
+    (32, (3, 3), 131072, False, torch.contiguous_format),  # config-4 queue: two sub-tiles per wave in the LDS-DMA kernel
+    (7, (4, 4), 2052, True, torch.contiguous_format),      # LDS-DMA kernel with a ragged last tile (2052 = 8 * 256 + 4)
 ])
 def test_loss_section_random_vs_oracle(B, hw, K, inc_bg, fmt):
     q, k, ma, mb, queue = _rand_case(B, hw, K, seed=B * 1000 + K)

@@ -28,6 +28,10 @@ q_pos = torch.nn.functional.normalize(torch.randn(32, C, device=dev, generator=g
 ext = torch.rand(32, 1, device=dev, generator=g)
 t_ins = timeit(lambda: ops.rowkey_infonce(q_pos, (1, C, 0, 1), 32, queue, ext, 0.2, 1.0 / 32), n=50)
 print(f"instance R=32 K={K}: fwd+grad {t_ins * 1e3:.1f} us (queue read once = {C * K * 4 / t_ins / 1e6:.0f} GB/s)")
+queue4 = torch.nn.functional.normalize(torch.randn(C, 131072, device=dev, generator=g), dim=0)
+q8, e8 = q_pos[:8].contiguous(), ext[:8].contiguous()
+t_ins4 = timeit(lambda: ops.rowkey_infonce(q8, (1, C, 0, 1), 8, queue4, e8, 0.2, 1.0 / 8), n=50)
+print(f"instance R=8 K=131072: fwd+grad {t_ins4 * 1e3:.1f} us (queue read once = {C * 131072 * 4 / t_ins4 / 1e6:.0f} GB/s)")
 # dense: config 4 (P=4096, B=8) and config 2 (P=196, B=32)
 for B, P in ((8, 4096), (8, 1024), (32, 196)):
     qd = torch.nn.functional.normalize(torch.randn(B, C, P, device=dev, generator=g), dim=1)
