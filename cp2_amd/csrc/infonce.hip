@@ -510,12 +510,6 @@ __global__ __launch_bounds__(256, 2) void rowkey_fwd_bf16x3_kernel(RowKeyArgs a,
 
 // Merge the per-split partials: lse, per-row loss, count of negatives above the
 // positive, d loss / d row (in the rows' own layout) and d loss / d extra logit.
-struct RowKeyFinArgs {
-    const float* part_m; const float* part_s; const int* part_cnt; const float* part_U; int S;
-    const float* extras; int NE; float inv_t; float grad_scale;
-    int R; int RP; int64_t d_sn, d_sx, d_sc;
-    float* lse; float* loss_rows; int* cnt_gt; float* drows; float* dE;
-};
 
 constexpr int FIN_CPW = 4;  // channels per wave in the finalize kernel: grid.y = CH / (4 * FIN_CPW) channel groups
 
@@ -763,6 +757,8 @@ CP2_API int cp2_rowkey_infonce_finalize(const float* part_m, const float* part_s
     if (C != CH) return CP2_ERR_UNSUPPORTED;
     RowKeyFinArgs a{part_m, part_s, part_cnt, part_U, nsplit, extras, NE, 1.0f / temperature, grad_scale,
                     R, RP, d_sn, d_sx, d_sc, lse, loss_rows, cnt_gt, drows, dE};
+    if (R <= 32 && nsplit >= 16)      // one launch: merge, gradient, per-row outputs and the mean (rowkey_small.hip)
+        return rowkey_small_finalize_launch(a, loss_mean, cp2_stream(stream));
     if (nsplit >= 16)
         hipLaunchKernelGGL(rowkey_finalize_spar_kernel, dim3(cp2_cdiv(R, 32), drows ? CH / FS_CPB : 1), dim3(32 * FS_SL), 0,
                            cp2_stream(stream), a);

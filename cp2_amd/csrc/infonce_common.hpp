@@ -21,6 +21,16 @@ struct RowKeyArgs {
     float* lnegT;                                                  // optional raw logits, key-major [K][R]
 };
 
+// Merge of the per-split partials: lse, per-row loss, count of negatives above the positive, d loss / d row (in the
+// rows' own layout) and d loss / d extra logit.
+struct RowKeyFinArgs {
+    const float* part_m; const float* part_s; const int* part_cnt; const float* part_U; int S;
+    const float* extras; int NE; float inv_t; float grad_scale;
+    int R; int RP; int64_t d_sn, d_sx, d_sc;
+    float* lse; float* loss_rows; int* cnt_gt; float* drows; float* dE;
+};
+
 // Small-R form (R <= 32 rows, K % 4 == 0, 16-byte aligned keys): rowkey_small.hip
 int rowkey_small_num_splits(int K, int* tiles_per_wg);
 int rowkey_small_launch(const RowKeyArgs& a, int nsplit, bool with_u, hipStream_t stream);
+int rowkey_small_finalize_launch(const RowKeyFinArgs& a, float* loss_mean, hipStream_t stream);

@@ -21,6 +21,7 @@
 // MFMA k-index of product 1: lane half h carries channel 64 h + t at step t (any bijection works as long as both
 // operands agree), so a lane's 64 row values are contiguous in memory.
 #include "infonce_common.hpp"
+#include <stdlib.h>
 
 constexpr int SM_WAVES = 8;
 constexpr int SM_KEYS = 32 * SM_WAVES;                 // keys per workgroup tile
@@ -61,8 +62,11 @@ __device__ __forceinline__ void lds_wait4x4(f32x4 (&v)[4]) {
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : "i"(N));
 }
 // group G of product 1: A values of steps t = 8 G .. 8 G + 7 (channel 64 h + t, this lane's key)
+// The sub-tile's 16 DMA pieces are issued in the order 0, 8, 1, 9, ... (piece i = channels 8 i .. 8 i + 7), so group G
+// needs everything up to the (2 G + 2)-th piece: vmcnt(14 - 2 G) -- product 1 starts while the rest of the sub-tile lands.
 template <int G>
 __device__ __forceinline__ void p1_read_group(float (&v)[8], const unsigned (&a1)[8]) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(14 - 2 * G) : "memory");
     lds_read_b32<(((8 * G + 0) >> 1) * 64 + 0) * 4>(v[0], a1[((8 * G + 0) >> 1) & 7]);
     lds_read_b32<(((8 * G + 1) >> 1) * 64 + 32) * 4>(v[1], a1[((8 * G + 1) >> 1) & 7]);
     lds_read_b32<(((8 * G + 2) >> 1) * 64 + 0) * 4>(v[2], a1[((8 * G + 2) >> 1) & 7]);
@@ -104,7 +108,7 @@ __device__ __forceinline__ void p2_step(f32x16 (&U)[4], f32x4& cur, f32x4& fill,
 }
 
 template <bool WITH_U>
-__global__ __launch_bounds__(64 * SM_WAVES) void rowkey_small_kernel(RowKeyArgs a, int tiles_per_wg) {
+__global__ __launch_bounds__(64 * SM_WAVES) void rowkey_small_kernel(RowKeyArgs a, int tiles_per_wg, int stagger) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -123,16 +127,15 @@ __global__ __launch_bounds__(64 * SM_WAVES) void rowkey_small_kernel(RowKeyArgs 
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.extras + (int64_t)rclamp * a.NE),
                                          (__attribute__((address_space(3))) void*)ebuf, 4, 0, 0);
     }
-    // (2) the row image (B operand of product 1).  EVERY wave copies all 32 rows into the one shared 16 KB region --
-    // identical bytes, so the overlapping writes are benign -- and then needs only its own vmcnt: still no barrier.
+    // (2) the row image (B operand of product 1), 16 KB shared by the 8 waves: wave w copies rows 4 w .. 4 w + 3.
     // Chunk (row rr, channel quad cq) sits in slot rr * 32 + (cq ^ rr): a lane's 16 chunks of channels 64 h .. + 63
     // are read by ds_read_b128 without bank conflicts.  Rows beyond R alias row 0 (finite data; their MFMA columns
     // are independent of the real rows and never written out).
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int rr = 2 * i + h, cq = r ^ rr;
+    for (int i = 0; i < 2; ++i) {
+        const int rr = 4 * w + 2 * i + h, cq = r ^ rr;
         const int rs = rr < a.R ? rr : 0;
-        glds16(a.rows + (int64_t)(rs / a.RP) * a.r_sn + (int64_t)(rs % a.RP) * a.r_sx + 4 * cq, Q + i * 256);
+        glds16(a.rows + (int64_t)(rs / a.RP) * a.r_sn + (int64_t)(rs % a.RP) * a.r_sx + 4 * cq, Q + (2 * w + i) * 256);
     }
     // (3) key sub-tiles through a buffer descriptor: per-lane byte offset in ONE VGPR per piece parity, the piece's
     // channel step (8 i K floats) in the scalar offset -- no 64-bit address per piece to keep alive across the loop.
@@ -145,17 +148,25 @@ __global__ __launch_bounds__(64 * SM_WAVES) void rowkey_small_kernel(RowKeyArgs 
         const int voffE = (c0 * a.K + (keyE < a.K ? keyE : 0)) * 4;      // K % 4 == 0: a 16-byte chunk is all or nothing;
         const int voffO = (c0 * a.K + (keyO < a.K ? keyO : 0)) * 4;      // chunks past K read key 0 and are masked later
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 16; ++j) {
+            const int i = (j >> 1) + 8 * (j & 1);              // 0, 8, 1, 9, ...: what product 1 needs first lands first
             __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (__attribute__((address_space(3))) void*)(T + i * 256), 16,
                                                      (i & 1) ? voffO : voffE, 8 * i * a.K * 4, 0, 0);
+        }
     };
     const int kfirst = blockIdx.x * tiles_per_wg * SM_KEYS + w * 32;                  // wave-uniform
+    // Waves 4-7 (the second wave of each SIMD) queue their sub-tile behind the first four: those then land at about
+    // half time and compute while the others' data is still streaming, instead of all eight finishing together.
+    if (w >= 4) {
+        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(4);
+    }
     if (kfirst < a.K) {
         issue_tile(kfirst);
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // everything issued before the sub-tile has landed
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    __builtin_amdgcn_s_barrier();                             // raw barrier (no vmcnt drain): all 8 parts of the row image are in LDS
     float bq[CH / 2];
     float pos_s;
     {
@@ -202,8 +213,6 @@ __global__ __launch_bounds__(64 * SM_WAVES) void rowkey_small_kernel(RowKeyArgs 
     for (int ti = 0; ti < tiles_per_wg; ++ti) {
         const int kbase = kfirst + ti * SM_KEYS;
         if (kbase >= a.K) break;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
 
         // product 1: S^T[key = rho(reg, h)][row = r]
         f32x16 acc = {0};
@@ -338,6 +347,122 @@ int rowkey_small_launch(const RowKeyArgs& a, int nsplit, bool with_u, hipStream_
         if (e_ != hipSuccess) return (int)e_;
         attr_set[with_u] = true;
     }
-    hipLaunchKernelGGL(kfn, dim3(nsplit), dim3(64 * SM_WAVES), SM_LDS, stream, a, tpw);
+    static int stagger = -1;                           // tuning knob (units of 256 cycles), default chosen by measurement
+    if (stagger < 0) {
+        const char* e = getenv("CP2_ROWKEY_STAGGER");
+        stagger = e ? atoi(e) : 4;
+    }
+    hipLaunchKernelGGL(kfn, dim3(nsplit), dim3(64 * SM_WAVES), SM_LDS, stream, a, tpw, stagger);
+    return cp2_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Merge of the S per-workgroup partials for R <= 32 rows, ONE launch (was: merge kernel + mean kernel, and three
+// dependent passes over the partials).  Workgroup = 1024 threads = (32 split lanes) x (32 rows); grid = CH / FS2_CPB
+// channel groups.  Every load a thread needs -- its S/32 partial maxima / sums / counts and its S/32 x FS2_CPB gradient
+// partials -- is issued up front (the addresses do not depend on each other), so the kernel is one memory round
+// trip plus three LDS reductions instead of a chain of dependent loops.  Workgroup 0 also writes the per-row outputs
+// and the batch mean of the loss.  Fixed reduction order: deterministic.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int FS2_CPB = 2, FS2_SL = 32, FS2_NS = 8;      // up to 32 * 8 = 256 splits per pass of the unrolled loads
+
+__global__ __launch_bounds__(32 * FS2_SL) void rowkey_small_finalize_kernel(RowKeyFinArgs a, float* __restrict__ loss_mean) {
+    __shared__ float red[FS2_SL][33];
+    __shared__ int redi[FS2_SL][33];
+    __shared__ float red2[FS2_CPB][FS2_SL][33];
+    const int r = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const bool ok = r < a.R;
+    const int rr = ok ? r : 0;
+    const int c0 = blockIdx.x * FS2_CPB;
+    float M = -INFINITY, z = 0.f, acc[FS2_CPB];
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < FS2_CPB; ++i) acc[i] = 0.f;
+    float e[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < a.NE; ++j) e[j] = a.extras[(int64_t)rr * a.NE + j] * a.inv_t;
+    // pass structure: S <= 256 is one pass (the common case); larger S accumulates pass by pass with a running maximum
+    for (int s0 = 0; s0 < a.S; s0 += FS2_SL * FS2_NS) {
+        float mv[FS2_NS], sv[FS2_NS], uv[FS2_CPB][FS2_NS];
+        int cv[FS2_NS];
+#pragma unroll
+        for (int j = 0; j < FS2_NS; ++j) {
+            const int s = s0 + sl + FS2_SL * j;
+            const bool v = s < a.S;
+            const int64_t o = (int64_t)(v ? s : 0) * a.R + rr;
+            mv[j] = a.part_m[o]; sv[j] = a.part_s[o]; cv[j] = a.part_cnt[o];
+            if (a.drows) {
+#pragma unroll
+                for (int i = 0; i < FS2_CPB; ++i) uv[i][j] = a.part_U[((int64_t)(v ? s : 0) * CH + c0 + i) * a.R + rr];
+            }
+            if (!v) { mv[j] = -INFINITY; sv[j] = 0.f; cv[j] = 0; }
+        }
+        float m_new = M;
+#pragma unroll
+        for (int j = 0; j < FS2_NS; ++j) m_new = fmaxf(m_new, mv[j]);
+        const float sc = (M == -INFINITY) ? 0.f : __expf(M - m_new);
+        z *= sc;
+#pragma unroll
+        for (int i = 0; i < FS2_CPB; ++i) acc[i] *= sc;
+#pragma unroll
+        for (int j = 0; j < FS2_NS; ++j) {
+            const float wj = (mv[j] == -INFINITY) ? 0.f : __expf(mv[j] - m_new);
+            z += sv[j] * wj;
+            cnt += cv[j];
+            if (a.drows) {
+#pragma unroll
+                for (int i = 0; i < FS2_CPB; ++i) acc[i] += uv[i][j] * wj;
+            }
+        }
+        M = m_new;
+    }
+    // this thread now holds (M, z, acc) of its own splits relative to its own maximum M; combine the 32 split lanes
+    red[sl][r] = M;
+    __syncthreads();
+    float Mg = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < FS2_SL; ++j) Mg = fmaxf(Mg, red[j][r]);
+    for (int j = 0; j < a.NE; ++j) Mg = fmaxf(Mg, e[j]);
+    const float f = (M == -INFINITY) ? 0.f : __expf(M - Mg);
+    __syncthreads();
+    red[sl][r] = z * f;
+    redi[sl][r] = cnt;
+#pragma unroll
+    for (int i = 0; i < FS2_CPB; ++i) red2[i][sl][r] = acc[i] * f;
+    __syncthreads();
+    float Z = 0.f;
+    int ctot = 0;
+#pragma unroll
+    for (int j = 0; j < FS2_SL; ++j) { Z += red[j][r]; ctot += redi[j][r]; }
+    for (int j = 0; j < a.NE; ++j) Z += __expf(e[j] - Mg);
+    for (int j = 1; j < a.NE; ++j) ctot += (e[j] > e[0]) ? 1 : 0;     // extra negatives also rank against the positive
+    const float lse = Mg + logf(Z);
+    if (a.drows && sl < FS2_CPB && ok) {                  // split lane sl finishes channel c0 + sl
+        float tot = 0.f;
+#pragma unroll
+        for (int j = 0; j < FS2_SL; ++j) tot += red2[sl][j][r];
+        float* d = a.drows + (int64_t)(r / a.RP) * a.d_sn + (int64_t)(r % a.RP) * a.d_sx;
+        d[(int64_t)(c0 + sl) * a.d_sc] = tot * __expf(Mg - lse) * a.grad_scale * a.inv_t;
+    }
+    if (blockIdx.x == 0 && sl == 0) {                     // one wave half: the per-row outputs and the batch mean
+        const float lrow = lse - e[0];
+        if (ok) {
+            a.lse[r] = lse;
+            a.loss_rows[r] = lrow;
+            a.cnt_gt[r] = ctot;
+            if (a.dE)
+                for (int j = 0; j < a.NE; ++j)
+                    a.dE[(int64_t)r * a.NE + j] = a.grad_scale * a.inv_t * (__expf(e[j] - lse) - (j == 0 ? 1.f : 0.f));
+        }
+        if (loss_mean) {
+            float t = ok ? lrow : 0.f;
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+            if (r == 0) loss_mean[0] = t / (float)a.R;
+        }
+    }
+}
+
+int rowkey_small_finalize_launch(const RowKeyFinArgs& a, float* loss_mean, hipStream_t stream) {
+    hipLaunchKernelGGL(rowkey_small_finalize_kernel, dim3(CH / FS2_CPB), dim3(32 * FS2_SL), 0, stream, a, loss_mean);
     return cp2_launch_status();
 }
