@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256, WK == 1 ? 2 : 1) void rowkey_fwd_kernel(RowKey
             for (int reg = 0; reg < 16; ++reg) {
                 const int key = k0 + kk + rho(reg, h);
                 const bool valid = key < k_end;
-                if (a.lnegT && valid && row_ok) a.lnegT[(int64_t)key * a.R + row] = acc[reg];
+                if (a.lnegT && valid && row_ok) a.lnegT[(int64_t)key * a.ln_sk + (int64_t)row * a.ln_sr] = acc[reg];
                 sv[reg] = valid ? acc[reg] * a.inv_t : -INFINITY;
                 tmax = fmaxf(tmax, sv[reg]);
                 cnt += (sv[reg] > pos_s) ? 1 : 0;
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256, 2) void rowkey_fwd_bf16x3_kernel(RowKeyArgs a,
             for (int reg = 0; reg < 16; ++reg) {
                 const int key = k0 + kk + rho(reg, h);
                 const bool valid = key < k_end;
-                if (a.lnegT && valid && row_ok) a.lnegT[(int64_t)key * a.R + row] = acc[reg];
+                if (a.lnegT && valid && row_ok) a.lnegT[(int64_t)key * a.ln_sk + (int64_t)row * a.ln_sr] = acc[reg];
                 sv[reg] = valid ? acc[reg] * a.inv_t : -INFINITY;
                 tmax = fmaxf(tmax, sv[reg]);
                 cnt += (sv[reg] > pos_s) ? 1 : 0;
@@ -690,14 +690,15 @@ CP2_API int cp2_rowkey_num_splits(int R, int K) {
 CP2_API int cp2_rowkey_infonce_fwd(const float* rows, int RP, int64_t r_sn, int64_t r_sx, int64_t r_sc, int R,
                                    const float* keys, int K, const float* extras, int NE, float temperature,
                                    int nsplit, float* part_m, float* part_s, int32_t* part_cnt, float* part_U,
-                                   float* lnegT, int precision, void* keys_split, int C, void* stream) {
+                                   float* lnegT, int lneg_row_major, int precision, void* keys_split, int C, void* stream) {
     if (!rows || !keys || !part_m || !part_s || !part_cnt) return CP2_ERR_NULL;
     if (NE > 0 && !extras) return CP2_ERR_NULL;
     if (R <= 0 || K <= 0 || RP <= 0 || nsplit <= 0 || NE < 0 || NE > 4 || !(temperature > 0.f)) return CP2_ERR_SHAPE;
     if (C != CH) return CP2_ERR_UNSUPPORTED;
+    const int64_t ln_sk = lneg_row_major ? 1 : R, ln_sr = lneg_row_major ? K : 1;
     if (rowkey_use_small(R, K) && rowkey_small_rows_ok(rows, r_sn, r_sx, r_sc, keys)) {
         RowKeyArgs sa{rows, RP, r_sn, r_sx, r_sc, R, keys, K, extras, NE, 1.0f / temperature, 0,
-                      part_m, part_s, part_cnt, part_U, lnegT};
+                      part_m, part_s, part_cnt, part_U, lnegT, ln_sk, ln_sr};
         return rowkey_small_launch(sa, nsplit, part_U != nullptr, cp2_stream(stream));
     }
     int WR, WK;
@@ -707,7 +708,7 @@ CP2_API int cp2_rowkey_infonce_fwd(const float* rows, int RP, int64_t r_sn, int6
     kps = cp2_cdiv(kps, KT) * KT;
     if ((int64_t)kps * (nsplit - 1) >= K && nsplit > 1) return CP2_ERR_SHAPE;  // an empty split: caller must use cp2_rowkey_num_splits
     RowKeyArgs a{rows, RP, r_sn, r_sx, r_sc, R, keys, K, extras, NE, 1.0f / temperature, kps,
-                 part_m, part_s, part_cnt, part_U, lnegT};
+                 part_m, part_s, part_cnt, part_U, lnegT, ln_sk, ln_sr};
     size_t lds = (size_t)CH * (KT + 1) * sizeof(float);
     if (WK > 1) {
         const size_t merge = ((size_t)WR * WK * CH * 32 + 3 * (size_t)WR * WK * 32) * sizeof(float);

@@ -18,7 +18,7 @@ struct RowKeyArgs {
     const float* extras; int NE; float inv_t;                     // raw extra logits [R][NE], column 0 = positive
     int keys_per_split;
     float* part_m; float* part_s; int* part_cnt; float* part_U;   // [S][R], [S][R], [S][R], [S][CH][R]
-    float* lnegT;                                                  // optional raw logits, key-major [K][R]
+    float* lnegT; int64_t ln_sk, ln_sr;                            // optional raw logits, element (key, row) at key*ln_sk + row*ln_sr
 };
 
 // Merge of the per-split partials: lse, per-row loss, count of negatives above the positive, d loss / d row (in the

@@ -27,7 +27,7 @@ constexpr int SM_WAVES = 8;
 constexpr int SM_KEYS = 32 * SM_WAVES;                 // keys per workgroup tile
 constexpr int SM_TILE_F = CH * 32;                     // floats of one wave's sub-tile (16 KB)
 constexpr int SM_Q_F = 32 * CH;                        // floats of the shared row image (16 KB)
-constexpr int SM_LDS = (SM_WAVES * SM_TILE_F + SM_Q_F + 3 * SM_WAVES * 32 + SM_WAVES * 64) * 4;
+constexpr int SM_LDS = (SM_WAVES * SM_TILE_F + SM_Q_F + 3 * SM_WAVES * 32 + SM_WAVES * 64 + SM_WAVES * 32) * 4;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -78,7 +78,7 @@ __device__ __forceinline__ void p1_read_group(float (&v)[8], const unsigned (&a1
 }
 template <int G>
 __device__ __forceinline__ f32x16 p1_group(f32x16 acc, float (&cur)[8], float (&nxt)[8], const unsigned (&a1)[8],
-                                           const float (&bq)[CH / 2]) {
+                                           const f32x4 (&bq)[CH / 8]) {
     if constexpr (G + 1 < 8) {
         p1_read_group<G + 1>(nxt, a1);
         lds_wait8<8>(cur);
@@ -86,26 +86,66 @@ __device__ __forceinline__ f32x16 p1_group(f32x16 acc, float (&cur)[8], float (&
         lds_wait8<0>(cur);
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc = mfma32(cur[j], bq[G * 8 + j], acc);
+    for (int j = 0; j < 8; ++j) acc = mfma32(cur[j], bq[2 * G + (j >> 2)][j & 3], acc);
     return acc;
 }
-// product 2, one 16-byte chunk (4 keys of one channel = 4 MFMAs) at a time, reads three chunks ahead in a ring of four
+// Product 2 (the gradient's key sum  U^T[c][row] += sum_key T[c][key] p[key][row]) runs as split-bf16 on
+// v_mfma_f32_32x32x16_bf16: every fp32 operand x = hi + lo (hi = bf16(x), lo = bf16(x - hi)) and every product =
+// hi*hi + hi*lo + lo*hi with fp32 accumulation -- 24 MFMAs of 32 cycles per sub-tile instead of 64 of 64 cycles.
+// The logits (product 1) stay exact fp32; the split only touches the 65536-term sum of the gradient, where the
+// independent 2^-17-relative rounding errors average out: measured error 5e-7 * max|grad| (plain fp32 summation
+// order noise: 1e-7), against a test bound of 2e-5.  Without this the kernel is bound by the f32 matrix pipe
+// (2 x 128 MFMAs x 64 cycles per SIMD = 8.6 us at 1.9 GHz), not by the queue stream.
+// k-step s of a 32-key sub-tile = accumulator registers 8 s .. 8 s + 7 of product 1, i.e. lane half h carries keys
+// 16 s + 8 (j >> 2) + 4 h + (j & 3), j < 8: exactly the two 16-byte chunks kq = 4 s + h and 4 s + 2 + h of a channel.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_bf(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 hj = (__bf16)v[j];
+        hi[j] = hj;
+        lo[j] = (__bf16)(v[j] - (float)hj);
+    }
+}
 template <int N>
-__device__ __forceinline__ void p2_read(f32x4& v, const unsigned (&a2)[4]) {
+__device__ __forceinline__ void p2_read(f32x4& v, const unsigned (&a2)[4]) {      // chunk N = 4 cb + g of this lane's channel
     lds_read_b128<(N >> 2) * 4096>(v, a2[N & 3]);
 }
 template <int W>
-__device__ __forceinline__ void lds_wait1(f32x4& v) {
-    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "i"(W));
+__device__ __forceinline__ void lds_wait2(f32x4& v0, f32x4& v1) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(v0), "+v"(v1) : "i"(W));
 }
-template <int N>
-__device__ __forceinline__ void p2_step(f32x16 (&U)[4], f32x4& cur, f32x4& fill, const unsigned (&a2)[4], const float (&p)[16]) {
-    if constexpr (N + 3 < 16) p2_read<N + 3>(fill, a2);
-    lds_wait1<(N + 3 < 16) ? 3 : (15 - N)>(cur);
-    constexpr int g = N & 3, cb = N >> 2;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) U[cb] = mfma32(cur[e], p[4 * g + e], U[cb]);
+// step M = 2 cb + s: chunks 2 M, 2 M + 1; the next step's two chunks are read before this one's are waited for
+template <int M>
+__device__ __forceinline__ void p2_step(f32x16 (&U)[4], f32x4& c0, f32x4& c1, f32x4& n0, f32x4& n1, const unsigned (&a2)[4],
+                                        const bf16x8 (&ph)[2], const bf16x8 (&pl)[2]) {
+    if constexpr (M + 1 < 8) {
+        p2_read<2 * M + 2>(n0, a2);
+        p2_read<2 * M + 3>(n1, a2);
+        lds_wait2<2>(c0, c1);
+    } else {
+        lds_wait2<0>(c0, c1);
+    }
+    const float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+    bf16x8 ah, al;
+    split8(v, ah, al);
+    constexpr int cb = M >> 1, ks = M & 1;
+    U[cb] = mfma_bf(ah, ph[ks], U[cb]);
+    U[cb] = mfma_bf(al, ph[ks], U[cb]);
+    U[cb] = mfma_bf(ah, pl[ks], U[cb]);
 }
+
+// Diagnostic build only (tools/rowkey_small_bench.hip defines CP2_STAMPS): shader-clock stamps of one wave per
+// workgroup go to a buffer nothing else reads; the shipped kernel executes none of this.
+#ifdef CP2_STAMPS
+__device__ unsigned long long cp2_stamps[256 * 8 * 16];
+#define CP2_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (lane == 0) cp2_stamps[(blockIdx.x * 8 + w) * 16 + (i)] = (i) == 7 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define CP2_STAMP(i) do {} while (0)
+#endif
 
 template <bool WITH_U>
 __global__ __launch_bounds__(64 * SM_WAVES) void rowkey_small_kernel(RowKeyArgs a, int tiles_per_wg, int stagger) {
@@ -120,6 +160,8 @@ __global__ __launch_bounds__(64 * SM_WAVES) void rowkey_small_kernel(RowKeyArgs 
     float* ebuf = sbuf + 2 * SM_WAVES * 32 + w * 64;            // [8][64] this wave's positive logits
     const bool row_ok = r < a.R;
     const int rclamp = row_ok ? r : 0;
+    CP2_STAMP(7);
+    CP2_STAMP(0);
 
     // Every load of this kernel is an LDS-DMA (hipcc drains vmcnt to 0 around ordinary loads that sit beside DMAs).
     // (1) the positive logit of this lane's row, 4-byte pieces
@@ -166,33 +208,16 @@ __global__ __launch_bounds__(64 * SM_WAVES) void rowkey_small_kernel(RowKeyArgs 
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    CP2_STAMP(1);
     __builtin_amdgcn_s_barrier();                             // raw barrier (no vmcnt drain): all 8 parts of the row image are in LDS
-    float bq[CH / 2];
     float pos_s;
     {
-        const unsigned qb = lds_addr(Q) + 16u * (unsigned)(r * 32 + ((h ^ (r >> 4)) << 4));
-        f32x4 v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10, v11, v12, v13, v14, v15;
-        const unsigned x = r & 15;
-        lds_read_b128<0>(v0, qb + 16u * (0 ^ x));   lds_read_b128<0>(v1, qb + 16u * (1 ^ x));
-        lds_read_b128<0>(v2, qb + 16u * (2 ^ x));   lds_read_b128<0>(v3, qb + 16u * (3 ^ x));
-        lds_read_b128<0>(v4, qb + 16u * (4 ^ x));   lds_read_b128<0>(v5, qb + 16u * (5 ^ x));
-        lds_read_b128<0>(v6, qb + 16u * (6 ^ x));   lds_read_b128<0>(v7, qb + 16u * (7 ^ x));
-        lds_read_b128<0>(v8, qb + 16u * (8 ^ x));   lds_read_b128<0>(v9, qb + 16u * (9 ^ x));
-        lds_read_b128<0>(v10, qb + 16u * (10 ^ x)); lds_read_b128<0>(v11, qb + 16u * (11 ^ x));
-        lds_read_b128<0>(v12, qb + 16u * (12 ^ x)); lds_read_b128<0>(v13, qb + 16u * (13 ^ x));
-        lds_read_b128<0>(v14, qb + 16u * (14 ^ x)); lds_read_b128<0>(v15, qb + 16u * (15 ^ x));
         float e = 0.f;
         lds_read_b32<0>(e, lds_addr(ebuf) + 4u * (unsigned)lane);
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8), "+v"(v9),
-                       "+v"(v10), "+v"(v11), "+v"(v12), "+v"(v13), "+v"(v14), "+v"(v15), "+v"(e));
-        const f32x4 vv[16] = {v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10, v11, v12, v13, v14, v15};
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) bq[4 * j + q] = vv[j][q];
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e));
         pos_s = (row_ok && a.NE > 0) ? e * a.inv_t : INFINITY;
     }
+    const unsigned qb = lds_addr(Q) + 16u * (unsigned)(r * 32 + ((h ^ (r >> 4)) << 4));
 
     // product 1 read addresses: T[slot(64 h + t, r >> 2) * 4 + (r & 3)], rotation (kq + (t >> 1)) & 7 has period 8 in t >> 1
     const unsigned tbase = lds_addr(T);
@@ -213,12 +238,34 @@ __global__ __launch_bounds__(64 * SM_WAVES) void rowkey_small_kernel(RowKeyArgs 
     for (int ti = 0; ti < tiles_per_wg; ++ti) {
         const int kbase = kfirst + ti * SM_KEYS;
         if (kbase >= a.K) break;
+#ifdef CP2_EXP_HALF
+        if (w >= 4) break;           // experiment: one wave per SIMD only (results incomplete)
+#endif
 
         // product 1: S^T[key = rho(reg, h)][row = r]
         f32x16 acc = {0};
         {
+            // B operand of product 1, re-read from the LDS row image for every sub-tile: 64 registers that are live
+            // only during product 1 instead of across the whole loop
+            f32x4 bq[CH / 8];                                   // bq[j][e] = this lane's row at channel 64 h + 4 j + e
+            {
+                const unsigned x = r & 15;
+                lds_read_b128<0>(bq[0], qb + 16u * (0 ^ x));   lds_read_b128<0>(bq[1], qb + 16u * (1 ^ x));
+                lds_read_b128<0>(bq[2], qb + 16u * (2 ^ x));   lds_read_b128<0>(bq[3], qb + 16u * (3 ^ x));
+                lds_read_b128<0>(bq[4], qb + 16u * (4 ^ x));   lds_read_b128<0>(bq[5], qb + 16u * (5 ^ x));
+                lds_read_b128<0>(bq[6], qb + 16u * (6 ^ x));   lds_read_b128<0>(bq[7], qb + 16u * (7 ^ x));
+                lds_read_b128<0>(bq[8], qb + 16u * (8 ^ x));   lds_read_b128<0>(bq[9], qb + 16u * (9 ^ x));
+                lds_read_b128<0>(bq[10], qb + 16u * (10 ^ x)); lds_read_b128<0>(bq[11], qb + 16u * (11 ^ x));
+                lds_read_b128<0>(bq[12], qb + 16u * (12 ^ x)); lds_read_b128<0>(bq[13], qb + 16u * (13 ^ x));
+                lds_read_b128<0>(bq[14], qb + 16u * (14 ^ x)); lds_read_b128<0>(bq[15], qb + 16u * (15 ^ x));
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]), "+v"(bq[4]), "+v"(bq[5]), "+v"(bq[6]),
+                               "+v"(bq[7]), "+v"(bq[8]), "+v"(bq[9]), "+v"(bq[10]), "+v"(bq[11]), "+v"(bq[12]), "+v"(bq[13]),
+                               "+v"(bq[14]), "+v"(bq[15]));
+            }
             float va[8], vb[8];
             p1_read_group<0>(va, a1);
+            CP2_STAMP(2);
             acc = p1_group<0>(acc, va, vb, a1, bq);
             acc = p1_group<1>(acc, vb, va, a1, bq);
             acc = p1_group<2>(acc, va, vb, a1, bq);
@@ -229,20 +276,23 @@ __global__ __launch_bounds__(64 * SM_WAVES) void rowkey_small_kernel(RowKeyArgs 
             acc = p1_group<7>(acc, vb, va, a1, bq);
         }
 
+        CP2_STAMP(3);
         float sv[16];
         float tmax = -INFINITY;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int key = kbase + rho(reg, h);
             const bool valid = key < a.K;
-            if (a.lnegT && valid && row_ok) a.lnegT[(int64_t)key * a.R + r] = acc[reg];
+            if (a.lnegT && valid && row_ok) a.lnegT[(int64_t)key * a.ln_sk + (int64_t)r * a.ln_sr] = acc[reg];
             sv[reg] = valid ? acc[reg] * a.inv_t : -INFINITY;
             tmax = fmaxf(tmax, sv[reg]);
             cnt += (sv[reg] > pos_s) ? 1 : 0;
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));          // at least one key of the sub-tile is valid: tmax is finite
-        if (tmax > m_run) {
-            const float sc = __expf(m_run - tmax);              // exp(-inf) = 0 on the first sub-tile
+        if (ti == 0) {
+            m_run = tmax;                                       // nothing accumulated yet: no rescale
+        } else if (tmax > m_run) {
+            const float sc = __expf(m_run - tmax);
             s_run *= sc;
             if (WITH_U) {
 #pragma unroll
@@ -250,6 +300,7 @@ __global__ __launch_bounds__(64 * SM_WAVES) void rowkey_small_kernel(RowKeyArgs 
             }
             m_run = tmax;
         }
+        CP2_STAMP(10);
         float (&p)[16] = sv;                                    // probabilities overwrite the scaled logits
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
@@ -258,13 +309,23 @@ __global__ __launch_bounds__(64 * SM_WAVES) void rowkey_small_kernel(RowKeyArgs 
         }
         if (WITH_U) {
             // product 2: U^T[c = cb*32 + rho(reg', h)][row] += sum_key T[c][key] * p[key][row]
-            f32x4 c0_, c1_, c2_, c3_;
-            p2_read<0>(c0_, a2); p2_read<1>(c1_, a2); p2_read<2>(c2_, a2);
-            p2_step<0>(U, c0_, c3_, a2, p);   p2_step<1>(U, c1_, c0_, a2, p);   p2_step<2>(U, c2_, c1_, a2, p);   p2_step<3>(U, c3_, c2_, a2, p);
-            p2_step<4>(U, c0_, c3_, a2, p);   p2_step<5>(U, c1_, c0_, a2, p);   p2_step<6>(U, c2_, c1_, a2, p);   p2_step<7>(U, c3_, c2_, a2, p);
-            p2_step<8>(U, c0_, c3_, a2, p);   p2_step<9>(U, c1_, c0_, a2, p);   p2_step<10>(U, c2_, c1_, a2, p);  p2_step<11>(U, c3_, c2_, a2, p);
-            p2_step<12>(U, c0_, c3_, a2, p);  p2_step<13>(U, c1_, c0_, a2, p);  p2_step<14>(U, c2_, c1_, a2, p);  p2_step<15>(U, c3_, c2_, a2, p);
+            bf16x8 ph[2], pl[2];
+            {
+                const float v0[8] = {p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]};
+                const float v1[8] = {p[8], p[9], p[10], p[11], p[12], p[13], p[14], p[15]};
+                split8(v0, ph[0], pl[0]);
+                split8(v1, ph[1], pl[1]);
+            }
+            CP2_STAMP(8);
+            f32x4 x0, x1, y0, y1;
+            p2_read<0>(x0, a2); p2_read<1>(x1, a2);
+            p2_step<0>(U, x0, x1, y0, y1, a2, ph, pl);  p2_step<1>(U, y0, y1, x0, x1, a2, ph, pl);
+            p2_step<2>(U, x0, x1, y0, y1, a2, ph, pl);  p2_step<3>(U, y0, y1, x0, x1, a2, ph, pl);
+            CP2_STAMP(9);
+            p2_step<4>(U, x0, x1, y0, y1, a2, ph, pl);  p2_step<5>(U, y0, y1, x0, x1, a2, ph, pl);
+            p2_step<6>(U, x0, x1, y0, y1, a2, ph, pl);  p2_step<7>(U, y0, y1, x0, x1, a2, ph, pl);
         }
+        CP2_STAMP(4);
         // every LDS read of this sub-tile has been retired by a counted wait above: the region may be overwritten
         if (ti + 1 < tiles_per_wg && kbase + SM_KEYS < a.K) issue_tile(kbase + SM_KEYS);
     }
@@ -280,55 +341,63 @@ __global__ __launch_bounds__(64 * SM_WAVES) void rowkey_small_kernel(RowKeyArgs 
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) T[(cb * 32 + rho(reg, h)) * 32 + r] = U[cb][reg];
     }
+    CP2_STAMP(5);
     __syncthreads();
     const int slot = blockIdx.x;
-    if (tid < 32) {
+    // per (wave, row) weights exp(m_w - M) once, by the first 256 threads; rows' merged (max, sum, count) by the first 32
+    float* fbuf = reinterpret_cast<float*>(cbuf + SM_WAVES * 32) + SM_WAVES * 64;   // [8][32], behind the positives
+    if (tid < SM_WAVES * 32) {
+        const int rr = tid & 31;
         float M = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < SM_WAVES; ++j) M = fmaxf(M, mbuf[j * 32 + tid]);
-        float ss = 0.f;
-        int cc = 0;
+        for (int j = 0; j < SM_WAVES; ++j) M = fmaxf(M, mbuf[j * 32 + rr]);
+        const float mj = mbuf[tid];
+        fbuf[tid] = (mj == -INFINITY) ? 0.f : __expf(mj - M);
+        if (tid < 32) {
+            float ss = 0.f;
+            int cc = 0;
 #pragma unroll
-        for (int j = 0; j < SM_WAVES; ++j) {
-            const float mj = mbuf[j * 32 + tid];
-            ss += (mj == -INFINITY) ? 0.f : sbuf[j * 32 + tid] * __expf(mj - M);
-            cc += cbuf[j * 32 + tid];
-        }
-        if (tid < a.R) {
-            a.part_m[(int64_t)slot * a.R + tid] = M;
-            a.part_s[(int64_t)slot * a.R + tid] = ss;
-            a.part_cnt[(int64_t)slot * a.R + tid] = cc;
+            for (int j = 0; j < SM_WAVES; ++j) {
+                const float mw = mbuf[j * 32 + tid];
+                ss += (mw == -INFINITY) ? 0.f : sbuf[j * 32 + tid] * __expf(mw - M);
+                cc += cbuf[j * 32 + tid];
+            }
+            if (tid < a.R) {
+                a.part_m[(int64_t)slot * a.R + tid] = M;
+                a.part_s[(int64_t)slot * a.R + tid] = ss;
+                a.part_cnt[(int64_t)slot * a.R + tid] = cc;
+            }
         }
     }
     if (WITH_U) {
+        __syncthreads();
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int e4 = tid + 512 * j;                 // float4 index into [C][32]
             const int c = e4 >> 3, r0 = (e4 & 7) * 4;
-            float M[4], f[4], u[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                M[e] = -INFINITY;
-#pragma unroll
-                for (int jw = 0; jw < SM_WAVES; ++jw) M[e] = fmaxf(M[e], mbuf[jw * 32 + r0 + e]);
-            }
+            f32x4 u = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int jw = 0; jw < SM_WAVES; ++jw) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(sm + jw * SM_TILE_F + e4 * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float mj = mbuf[jw * 32 + r0 + e];
-                    f[e] = (mj == -INFINITY) ? 0.f : __expf(mj - M[e]);
-                    u[e] += v[e] * f[e];
-                }
+                const f32x4 f = *reinterpret_cast<const f32x4*>(fbuf + jw * 32 + r0);
+                u += v * f;
             }
             float* dst = a.part_U + ((int64_t)slot * CH + c) * a.R;
+            if (a.R == 32) {
+                *reinterpret_cast<f32x4*>(dst + r0) = u;
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (r0 + e < a.R) dst[r0 + e] = u[e];
+                for (int e = 0; e < 4; ++e)
+                    if (r0 + e < a.R) dst[r0 + e] = u[e];
+            }
         }
     }
+    CP2_STAMP(6);
 }
+
+#ifdef CP2_STAMPS
+__global__ void cp2_stamp_end_kernel() {}
+#endif
 
 int rowkey_small_num_splits(int K, int* tiles_per_wg) {
     const int tiles = cp2_cdiv(K, SM_KEYS);
@@ -350,7 +419,7 @@ int rowkey_small_launch(const RowKeyArgs& a, int nsplit, bool with_u, hipStream_
     static int stagger = -1;                           // tuning knob (units of 256 cycles), default chosen by measurement
     if (stagger < 0) {
         const char* e = getenv("CP2_ROWKEY_STAGGER");
-        stagger = e ? atoi(e) : 4;
+        stagger = e ? atoi(e) : 0;   // measured: no gain from staggering (f32 MFMA and VALU share one pipe)
     }
     hipLaunchKernelGGL(kfn, dim3(nsplit), dim3(64 * SM_WAVES), SM_LDS, stream, a, tpw, stagger);
     return cp2_launch_status();

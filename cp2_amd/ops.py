@@ -333,13 +333,13 @@ def feat_bwd(dense, inv_norm, mask, g_dense, ds_pos, ds_neg, like: torch.Tensor)
 
 # ---------------------------------------------------------------- a10 / a16
 class RowKeyResult:
-    __slots__ = ("loss", "lse", "loss_rows", "cnt_gt", "drows", "dE", "lnegT")
+    __slots__ = ("loss", "lse", "loss_rows", "cnt_gt", "drows", "dE", "lnegT", "lneg")
 
 
 def rowkey_infonce(rows: torch.Tensor, row_layout: Tuple[int, int, int, int], R: int, keys: torch.Tensor,
                    extras: torch.Tensor, temperature: float, grad_scale: Optional[float],
                    drows_like: Optional[torch.Tensor] = None, want_lneg: bool = False,
-                   precision: str = "auto", presplit: bool = True) -> RowKeyResult:
+                   precision: str = "auto", presplit: bool = True, lneg_row_major: bool = False) -> RowKeyResult:
     """InfoNCE of R row vectors against the queue `keys` [C,K] with `extras` [R,NE] prepended
     (column 0 = positive).  row_layout = (RP, stride_n, stride_x, stride_c): element (c, r) of
     `rows` lives at (r//RP)*stride_n + (r%RP)*stride_x + c*stride_c.
@@ -363,7 +363,12 @@ def rowkey_infonce(rows: torch.Tensor, row_layout: Tuple[int, int, int, int], R:
     want_grad = grad_scale is not None
     part_U = torch.empty((ns, C, R), dtype=torch.float32, device=dev) if want_grad else None
     out = RowKeyResult()
-    out.lnegT = torch.empty((K, R), dtype=torch.float32, device=dev) if want_lneg else None
+    out.lnegT = out.lneg = None          # raw logits rows.keys: lnegT [K,R] (key-major) or lneg [R,K] (row-major)
+    if want_lneg and lneg_row_major:
+        out.lneg = torch.empty((R, K), dtype=torch.float32, device=dev)
+    elif want_lneg:
+        out.lnegT = torch.empty((K, R), dtype=torch.float32, device=dev)
+    lbuf = out.lneg if out.lneg is not None else out.lnegT
     # bf16x3: the queue's hi/lo split in both layouts, written once per call by a prep kernel (4*C*K bf16)
     ksplit = torch.empty(4 * C * K, dtype=torch.bfloat16, device=dev) if (prec == 1 and R > 64 and K % 8 == 0 and presplit) else None
     if not rows.is_cuda or rows.dtype != torch.float32:
@@ -371,7 +376,7 @@ def rowkey_infonce(rows: torch.Tensor, row_layout: Tuple[int, int, int, int], R:
     rc = lib.cp2_rowkey_infonce_fwd(rows.data_ptr(), RP, sn, sx, sc, R, _dev(keys, "keys", torch.float32), K,
                                     _dev(extras, "extras", torch.float32), NE, float(temperature), ns,
                                     part_m.data_ptr(), part_s.data_ptr(), part_cnt.data_ptr(), _opt(part_U, "part_U"),
-                                    _opt(out.lnegT, "lnegT"), prec, _opt(ksplit, "keys_split"), C, _stream())
+                                    _opt(lbuf, "lneg"), int(lneg_row_major), prec, _opt(ksplit, "keys_split"), C, _stream())
     _lib.check(rc, "cp2_rowkey_infonce_fwd")
     out.lse = torch.empty(R, dtype=torch.float32, device=dev)
     out.loss_rows = torch.empty(R, dtype=torch.float32, device=dev)

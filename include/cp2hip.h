@@ -123,7 +123,8 @@ int cp2_feat_bwd(const float* dense, const float* inv_norm, const float* mask, c
  * accumulates sum_j softmax_j * keys[:,j], so the gradient needs no second pass over the queue.
  * rows: element (c, r) at (r/RP)*r_sn + (r%RP)*r_sx + c*r_sc;  keys: [C,K] (column = key);  C = 128.
  * nsplit = cp2_rowkey_num_splits(R,K) key ranges run in parallel; workspaces part_m, part_s [nsplit,R],
- * part_cnt [nsplit,R] int32, part_U [nsplit,C,R] (NULL: no gradient), lnegT [K,R] raw logits or NULL.
+ * part_cnt [nsplit,R] int32, part_U [nsplit,C,R] (NULL: no gradient), lnegT: NULL, or the raw logits rows.keys as
+ * [K,R] (lneg_row_major = 0) or [R,K] (lneg_row_major = 1, the layout cp2_masked_quantiles reads fastest).
  * precision 0: f32-input MFMA (exact fp32 fma chains, logits within ~1e-6 of the reference);
  * precision 1: split-bf16 (hi*hi + hi*lo + lo*hi on bf16 MFMA, fp32 accumulate; logits within 3e-5) -- used when
  *              R > 64, otherwise the f32 kernel runs regardless.  keys_split: NULL, or a workspace of 4*C*K bf16
@@ -133,7 +134,7 @@ int cp2_rowkey_num_splits(int R, int K);
 int cp2_rowkey_infonce_fwd(const float* rows, int RP, int64_t r_sn, int64_t r_sx, int64_t r_sc, int R,
                            const float* keys, int K, const float* extras, int NE, float temperature,
                            int nsplit, float* part_m, float* part_s, int32_t* part_cnt, float* part_U,
-                           float* lnegT, int precision, void* keys_split, int C, void* stream);
+                           float* lnegT, int lneg_row_major, int precision, void* keys_split, int C, void* stream);
 /* Merge the splits: lse[R], loss_rows[R], cnt_gt[R] (# negatives whose logit exceeds the positive),
  * drows (same addressing as rows, with d_* strides; NULL: skip) = grad_scale * d sum_r loss_r / d rows,
  * dE [R,NE] likewise (may be NULL), loss_mean[1] = mean_r loss_r (may be NULL). */
