@@ -1,10 +1,14 @@
 // a15: logging statistics that the reference obtains by sorting every step on every rank --
-//   tools/correlation_mapping.py:16-53  per-sample nanquantile([.25,.5,.75]) and nanmean of the positive /
-//                                       negative dense scores (pairs selected by mask_a[x]*mask_b[y])
+//   tools/correlation_mapping.py:16-53  per-sample nanquantile([.25,.5,.75]) of the positive / negative dense
+//                                       scores (pairs selected by mask_a[x]*mask_b[y])
 //   builder.py:1399-1406                row quantiles of the b x K queue logits
-// Exact order statistics without sorting: one workgroup per (row, quantile) runs a 4-pass radix select
-// (8 bits per pass, LDS histogram) on the order-preserving integer image of the floats, then interpolates
-// exactly as torch.quantile(..., interpolation='linear') does:  rank = q*(n-1) in fp32, lerp(v_lo, v_hi, frac).
+// Exact order statistics without sorting: ONE workgroup per row finds all requested quantiles together by a
+// three-pass radix select (12 + 10 + 10 bits of the order-preserving integer image of the floats, LDS histograms),
+// then interpolates exactly as torch.quantile(..., interpolation='linear') does:
+//   rank = q*(n-1) in fp32, lerp(v_lo, v_hi, frac).
+// The interpolation partner (the next larger element) comes out of the last pass for free: it is the same key again
+// (multiplicity), the next non-empty bin of the last histogram, or the smallest key above the 22-bit prefix, which
+// that pass tracks with a running minimum.  (Round 1 ran one workgroup per (row, quantile) and six passes each.)
 #include "common.hpp"
 #include <math.h>
 
@@ -25,120 +29,169 @@ __device__ __forceinline__ float key2f(unsigned k) {
 }
 
 constexpr int QT = 1024;      // threads per workgroup
-constexpr int QU = 4;         // elements in flight per thread (the passes are load-latency bound otherwise)
+constexpr int QMAX = 4;       // quantiles per call
+constexpr int QB0 = 4096, QB1 = 1024;
 
-// One workgroup per (row, quantile):
-//   pass 0        count kept elements
-//   passes 1..4   radix select, 8 bits each, LDS histogram
-//   pass 5        for the interpolation partner: #elements <= v_lo and the smallest element above it
-// Masks are staged in LDS and the (x, y) pixel pair of element i is advanced incrementally (no division per
-// element); histogram updates are run-length compressed per thread (cosine logits share their top byte, so the
-// first pass would otherwise serialise on two LDS bins); QU independent loads per thread per iteration.
-__global__ __launch_bounds__(QT) void masked_quantile_kernel(QuantArgs a) {
+// inclusive prefix sum of one unsigned per thread over the 1024 threads of the workgroup (wtot: 16 words of LDS)
+__device__ __forceinline__ unsigned block_scan_incl(unsigned v, unsigned* wtot) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned t = (unsigned)__shfl_up((int)incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    __syncthreads();                                       // wtot may still be read by the previous scan
+    if (lane == 63) wtot[w] = incl;
+    __syncthreads();
+    unsigned base = 0;
+    for (int j = 0; j < w; ++j) base += wtot[j];
+    return incl + base;
+}
+
+__global__ __launch_bounds__(QT) void quantiles_kernel(QuantArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char q_smem[];
-    __shared__ unsigned hist[256];
-    __shared__ unsigned sh_prefix, sh_k, sh_le, sh_min, sh_cnt;
+    __shared__ unsigned hist0[QB0];
+    __shared__ unsigned hist[QMAX][QB1];
+    __shared__ unsigned wtot[16];
+    __shared__ unsigned sh_prefix[QMAX], sh_k[QMAX], sh_min[QMAX], sh_next[QMAX], sh_n;
     float* lma = reinterpret_cast<float*>(q_smem);
     float* lmb = lma + (a.want >= 0 ? a.P : 0);
-    const int r = blockIdx.x, qi = blockIdx.y, tid = threadIdx.x;
+    const int r = blockIdx.x, tid = threadIdx.x, NQ = a.NQ;
     const float* row = a.x + (int64_t)r * a.s_row;
     const bool masked = a.want >= 0;
     if (masked) {
         for (int i = tid; i < a.P; i += QT) { lma[i] = a.mask_a[(int64_t)r * a.P + i]; lmb[i] = a.mask_b[(int64_t)r * a.P + i]; }
     }
-    if (tid == 0) sh_cnt = 0;
+    for (int i = tid; i < QB0; i += QT) hist0[i] = 0;
     __syncthreads();
-    const int dx = masked ? QT / a.P : 0, dy = masked ? QT % a.P : 0;
-    const int x_start = masked ? tid / a.P : 0, y_start = masked ? tid % a.P : 0;
+    const bool vec = a.s_elem == 1 && ((reinterpret_cast<uintptr_t>(row) & 15u) == 0);
     auto keep_at = [&](int x, int y, float v) -> bool {
         if (v != v) return false;                          // nanquantile ignores NaN
         if (!masked) return true;
         return ((lma[x] * lmb[y]) != 0.f) == (a.want != 0);
     };
-#define CP2_Q_FOREACH(BODY)                                                                  \
-    {                                                                                        \
-        int x_ = x_start, y_ = y_start;                                                      \
-        for (int i0 = tid; i0 < a.N; i0 += QU * QT) {                                        \
-            float vv[QU];                                                                    \
-            _Pragma("unroll") for (int u = 0; u < QU; ++u) {                                 \
-                const int i = i0 + u * QT;                                                   \
-                vv[u] = i < a.N ? row[(int64_t)i * a.s_elem] : NAN;                          \
-            }                                                                                \
-            _Pragma("unroll") for (int u = 0; u < QU; ++u) {                                 \
-                const float v = vv[u];                                                       \
-                if (keep_at(x_, y_, v)) { BODY }                                             \
-                if (masked) { x_ += dx; y_ += dy; if (y_ >= a.P) { y_ -= a.P; ++x_; } }      \
-            }                                                                                \
-        }                                                                                    \
+    // Visit every kept element of the row once: 16-byte loads when the row is contiguous, four loads in flight otherwise.
+#define CP2_Q_FOREACH(BODY)                                                                              \
+    if (vec) {                                                                                           \
+        const int n4 = (a.N + 3) >> 2;                                                                   \
+        for (int i4 = tid; i4 < n4; i4 += QT) {                                                          \
+            const int i0 = i4 * 4;                                                                       \
+            float vv[4];                                                                                 \
+            if (i0 + 3 < a.N) {                                                                          \
+                const float4 t4 = *reinterpret_cast<const float4*>(row + i0);                            \
+                vv[0] = t4.x; vv[1] = t4.y; vv[2] = t4.z; vv[3] = t4.w;                                  \
+            } else {                                                                                     \
+                _Pragma("unroll") for (int u = 0; u < 4; ++u) vv[u] = (i0 + u < a.N) ? row[i0 + u] : NAN; \
+            }                                                                                            \
+            int x_ = masked ? i0 / a.P : 0, y_ = masked ? i0 % a.P : 0;                                  \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                              \
+                const float v = vv[u];                                                                   \
+                if (keep_at(x_, y_, v)) { BODY }                                                         \
+                if (masked && ++y_ >= a.P) { y_ = 0; ++x_; }                                             \
+            }                                                                                            \
+        }                                                                                                \
+    } else {                                                                                             \
+        for (int i0 = tid; i0 < a.N; i0 += 4 * QT) {                                                     \
+            float vv[4];                                                                                 \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                              \
+                const int i = i0 + u * QT;                                                               \
+                vv[u] = i < a.N ? row[(int64_t)i * a.s_elem] : NAN;                                      \
+            }                                                                                            \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                              \
+                const int i = i0 + u * QT;                                                               \
+                const float v = vv[u];                                                                   \
+                if (keep_at(masked ? i / a.P : 0, masked ? i % a.P : 0, v)) { BODY }                     \
+            }                                                                                            \
+        }                                                                                                \
     }
-    unsigned c = 0;
-    CP2_Q_FOREACH(++c;)
-    c = (unsigned)wave_sum_i((int)c);
-    if ((tid & 63) == 0 && c) atomicAdd(&sh_cnt, c);
+
+    // ---- pass 0: top 12 bits, one histogram for all quantiles (its total is n)
+    CP2_Q_FOREACH(atomicAdd(&hist0[f2key(v) >> 20], 1u);)
     __syncthreads();
-    const unsigned n = sh_cnt;
-    if (n == 0) {
-        if (tid == 0) a.out[(int64_t)qi * a.R + r] = NAN;
-        return;
-    }
-    const float rank = a.q[qi] * (float)(n - 1);
-    const float lo_f = floorf(rank);
-    const unsigned lo = (unsigned)lo_f;
-    const float w = rank - lo_f;
-    if (tid == 0) { sh_prefix = 0; sh_k = lo; }
-    for (int pass = 3; pass >= 0; --pass) {
-        for (int i = tid; i < 256; i += QT) hist[i] = 0;
+    {
+        const unsigned h0 = hist0[4 * tid], h1 = hist0[4 * tid + 1], h2 = hist0[4 * tid + 2], h3 = hist0[4 * tid + 3];
+        const unsigned tot = h0 + h1 + h2 + h3;
+        const unsigned incl = block_scan_incl(tot, wtot), excl = incl - tot;
+        if (tid == QT - 1) sh_n = incl;
         __syncthreads();
-        const unsigned prefix = sh_prefix, hi_mask = pass == 3 ? 0u : (0xFFFFFFFFu << (8 * (pass + 1)));
-        unsigned run_bin = 0, run_cnt = 0;
+        const unsigned n = sh_n;
+        if (n == 0) {
+            if (tid < NQ) a.out[(int64_t)tid * a.R + r] = NAN;
+            return;
+        }
+        for (int j = 0; j < NQ; ++j) {
+            const unsigned lo = (unsigned)floorf(a.q[j] * (float)(n - 1));
+            if (lo >= excl && lo < incl) {
+                unsigned kk = lo - excl, b = 4 * tid;
+                if (kk >= h0) { kk -= h0; ++b; if (kk >= h1) { kk -= h1; ++b; if (kk >= h2) { kk -= h2; ++b; } } }
+                sh_prefix[j] = b;
+                sh_k[j] = kk;
+            }
+        }
+    }
+    // ---- passes 1 and 2: ten more bits each, one histogram per quantile
+    for (int pass = 1; pass <= 2; ++pass) {
+        for (int i = tid; i < QMAX * QB1; i += QT) (&hist[0][0])[i] = 0;
+        if (tid < QMAX) { sh_min[tid] = 0xFFFFFFFFu; sh_next[tid] = 0xFFFFFFFFu; }
+        __syncthreads();
+        unsigned pre[QMAX], mn[QMAX];
+#pragma unroll
+        for (int j = 0; j < QMAX; ++j) { pre[j] = j < NQ ? sh_prefix[j] : 0xFFFFFFFFu; mn[j] = 0xFFFFFFFFu; }
+        const int sh = pass == 1 ? 20 : 10;
         CP2_Q_FOREACH(
             const unsigned k = f2key(v);
-            if ((k & hi_mask) == prefix) {
-                const unsigned bin = (k >> (8 * pass)) & 255u;
-                if (bin == run_bin) ++run_cnt;
-                else { if (run_cnt) atomicAdd(&hist[run_bin], run_cnt); run_bin = bin; run_cnt = 1; }
+            const unsigned top = k >> sh;
+            const unsigned bin = (k >> (sh - 10)) & (QB1 - 1);
+            _Pragma("unroll") for (int j = 0; j < QMAX; ++j) {
+                if (top == pre[j]) atomicAdd(&hist[j][bin], 1u);
+                else if (pass == 2 && j < NQ && top > pre[j]) mn[j] = min(mn[j], k);
             })
-        if (run_cnt) atomicAdd(&hist[run_bin], run_cnt);
-        __syncthreads();
-        if (tid < 64) {   // wave 0 finds the bin holding rank sh_k: lane l owns bins 4l..4l+3, prefix sums by shuffles
-            const unsigned h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
-            const unsigned tot = h0 + h1 + h2 + h3;
-            unsigned incl = tot;
+        if (pass == 2) {
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const unsigned t = (unsigned)__shfl_up((int)incl, off, 64);
-                if (tid >= off) incl += t;
+            for (int j = 0; j < QMAX; ++j) {
+                unsigned m = mn[j];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, off, 64));
+                if ((tid & 63) == 0 && m != 0xFFFFFFFFu) atomicMin(&sh_min[j], m);
             }
-            const unsigned excl = incl - tot, kk0 = sh_k;
+        }
+        __syncthreads();
+        for (int j = 0; j < NQ; ++j) {
+            const unsigned hv = hist[j][tid];
+            const unsigned incl = block_scan_incl(hv, wtot), excl = incl - hv;
+            const unsigned kk0 = sh_k[j];
+            __syncthreads();                               // everyone has read sh_k[j] before it is rewritten
             if (kk0 >= excl && kk0 < incl) {
-                unsigned kk = kk0 - excl, bsel = 4 * tid;
-                if (kk >= h0) { kk -= h0; ++bsel; if (kk >= h1) { kk -= h1; ++bsel; if (kk >= h2) { kk -= h2; ++bsel; } } }
-                sh_k = kk;
-                sh_prefix = prefix | (bsel << (8 * pass));
+                sh_prefix[j] = (pre[j] << 10) | (unsigned)tid;
+                sh_k[j] = kk0 - excl;
+            }
+            __syncthreads();
+            if (pass == 2) {
+                // the next non-empty bin above the selected one (the partner when the selected key is not repeated)
+                const unsigned sel = sh_prefix[j] & (QB1 - 1);
+                if (hv != 0 && (unsigned)tid > sel) atomicMin(&sh_next[j], (unsigned)tid);
             }
         }
         __syncthreads();
     }
-    const unsigned key_lo = sh_prefix;
-    const float v_lo = key2f(key_lo);
-    float v_hi = v_lo;
-    if (w != 0.f) {
-        if (tid == 0) { sh_le = 0; sh_min = 0xFFFFFFFFu; }
-        __syncthreads();
-        unsigned le = 0, mn = 0xFFFFFFFFu;
-        CP2_Q_FOREACH(
-            const unsigned k = f2key(v);
-            if (k <= key_lo) ++le; else mn = min(mn, k);)
-        le = (unsigned)wave_sum_i((int)le);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) mn = min(mn, (unsigned)__shfl_xor((int)mn, off, 64));
-        if ((tid & 63) == 0) { if (le) atomicAdd(&sh_le, le); atomicMin(&sh_min, mn); }
-        __syncthreads();
-        if (sh_le <= lo + 1) v_hi = key2f(sh_min);
-    }
-    if (tid == 0) {
+    if (tid < NQ) {
+        const int j = tid;
+        const unsigned n = sh_n;
+        const float rank = a.q[j] * (float)(n - 1);
+        const float lo_f = floorf(rank), w = rank - lo_f;
+        const unsigned key_lo = sh_prefix[j];
+        const float v_lo = key2f(key_lo);
+        float v_hi = v_lo;
+        if (w != 0.f) {
+            const unsigned mult = hist[j][key_lo & (QB1 - 1)];
+            if (sh_k[j] + 1 >= mult) {                     // the element of rank lo + 1 is a larger key
+                if (sh_next[j] != 0xFFFFFFFFu) v_hi = key2f((key_lo & ~(unsigned)(QB1 - 1)) | sh_next[j]);
+                else if (sh_min[j] != 0xFFFFFFFFu) v_hi = key2f(sh_min[j]);
+            }
+        }
         const float d = v_hi - v_lo;                         // at::lerp: w < 0.5 ? a + w*(b-a) : b - (b-a)*(1-w)
-        a.out[(int64_t)qi * a.R + r] = (w < 0.5f) ? v_lo + w * d : v_hi - d * (1.f - w);
+        a.out[(int64_t)j * a.R + r] = (w < 0.5f) ? v_lo + w * d : v_hi - d * (1.f - w);
     }
 #undef CP2_Q_FOREACH
 }
@@ -148,10 +201,16 @@ CP2_API int cp2_masked_quantiles(const float* x, int64_t stride_row, int64_t str
                                  float* out, void* stream) {
     if (!x || !q || !out) return CP2_ERR_NULL;
     if (R <= 0 || N <= 0 || NQ <= 0) return CP2_ERR_SHAPE;
+    if (NQ > QMAX) return CP2_ERR_UNSUPPORTED;
     if (want >= 0 && (!mask_a || !mask_b || P <= 0 || (int64_t)P * P != N)) return CP2_ERR_SHAPE;
-    if (want >= 0 && P > 16384) return CP2_ERR_UNSUPPORTED;
+    if (want >= 0 && P > 8192) return CP2_ERR_UNSUPPORTED;
     QuantArgs a{x, stride_row, stride_elem, N, mask_a, mask_b, P, want, q, NQ, out, R};
     const size_t lds = want >= 0 ? 2 * (size_t)P * sizeof(float) : 0;
-    hipLaunchKernelGGL(masked_quantile_kernel, dim3(R, NQ), dim3(QT), lds, cp2_stream(stream), a);
+    if (lds > 32768) {
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(quantiles_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e_ != hipSuccess) return (int)e_;
+    }
+    hipLaunchKernelGGL(quantiles_kernel, dim3(R), dim3(QT), lds, cp2_stream(stream), a);
     return cp2_launch_status();
 }

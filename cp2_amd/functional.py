@@ -28,7 +28,7 @@ class CP2LossOutputs:
     q_pos: torch.Tensor
     dense_sample: torch.Tensor       # [B,8] Sa, Sb, loss_n, mean +score, mean -score, arg-max label
     instance_pos: torch.Tensor       # [B] raw positive logit q_pos.k_pos
-    lnegT: Optional[torch.Tensor] = None                  # [K,B] raw queue logits (want_lneg / want_quartiles)
+    lneg: Optional[torch.Tensor] = None                   # [B,K] raw queue logits (want_lneg / want_quartiles)
     # logging quartiles (want_quartiles): [3,B] each = torch.(nan)quantile(..., [.25,.5,.75]) of the reference
     dense_pos_quartiles: Optional[torch.Tensor] = None    # tools/correlation_mapping.py:16-53, positive pairs
     dense_neg_quartiles: Optional[torch.Tensor] = None    # ... negative pairs
@@ -51,7 +51,7 @@ class _CP2LossFn(torch.autograd.Function):
         ext = extras if include_background else extras[:, :1].contiguous()
         C = q_pos.shape[1]
         ins = ops.rowkey_infonce(q_pos, (1, C, 0, 1), B, queue, ext, temp_global,
-                                 grad_scale=(1.0 / B) if need_grad else None, want_lneg=want_lneg)
+                                 grad_scale=(1.0 / B) if need_grad else None, want_lneg=want_lneg, lneg_row_major=True)
         den = ops.dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temp_local, ids, weights, want_logits=want_quart)
         loss = ins.loss + den.loss * lmbd_dense
         if need_grad:
@@ -68,13 +68,12 @@ class _CP2LossFn(torch.autograd.Function):
         acc5 = (ins.cnt_gt < 5).float().mean() * 100.0
         outs = (loss, ins.loss, den.loss, den.acc, acc1, acc5, k_pos, q_pos, den.sample_scal, extras[:, 0].contiguous())
         if want_lneg:
-            outs = outs + (ins.lnegT,)
+            outs = outs + (ins.lneg,)
         if want_quart:
             K = queue.shape[1]
             outs = outs + (ops.masked_quantiles(den.logits, P * P, 1, B, P * P, mask_a=mask_a, mask_b=mask_b, want=1),
                            ops.masked_quantiles(den.logits, P * P, 1, B, P * P, mask_a=mask_a, mask_b=mask_b, want=0),
-                           # the kernel wants contiguous rows: one 8 MB transpose beats 18 strided passes (356 -> ~40 us)
-                           ops.masked_quantiles(ins.lnegT.t().contiguous(), K, 1, B, K), ins.lnegT.mean(0))
+                           ops.masked_quantiles(ins.lneg, K, 1, B, K), ins.lneg.mean(1))
         ctx.mark_non_differentiable(*outs[1:])
         return outs
 
@@ -101,7 +100,7 @@ def cp2_loss_section(q_feat: torch.Tensor, k_feat: torch.Tensor, mask_a: torch.T
     res = CP2LossOutputs(*outs[:10])
     i = 10
     if want_lneg or want_quartiles:
-        res.lnegT = outs[i]
+        res.lneg = outs[i]
         i += 1
     if want_quartiles:
         res.dense_pos_quartiles, res.dense_neg_quartiles, res.instance_neg_quartiles, res.instance_neg_mean = outs[i:i + 4]
