@@ -37,7 +37,7 @@ SIGNATURES = {
                                     c_int64, c_int64, _P, _P, _P, _P, _P, _P, c_int, _P],
     "cp2_dense_num_splits": [c_int, c_int],
     "cp2_dense_infonce_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, _P, _P, _P, _P,
-                              _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
+                              _P, _P, _P, _P, _P, _P, c_int, c_float, _P, c_int, c_int, c_int, _P],
     "cp2_sgd_flat": [_P, _P, _P, _P, c_int, _P, _P, c_float, _P, c_float, c_float, _P],
     "cp2_bf16_image": [_P, _P, c_int64, _P],
     "cp2_wgrad1x1_num_splits": [c_int, c_int, c_int],
@@ -46,8 +46,9 @@ SIGNATURES = {
     "cp2_bn_fwd": [_P, _P, _P, _P, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P],
     "cp2_bn_bwd": [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, _P],
     "cp2_masked_quantiles": [_P, c_int64, c_int64, c_int, c_int, _P, _P, c_int, c_int, _P, c_int, _P, _P],
+    "cp2_masked_quantiles_multi": [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P],
     "cp2_dense_infonce_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, _P, _P, c_float,
-                              _P, _P, c_int, c_int, c_int, _P],
+                              _P, _P, c_int, c_float, _P, c_int, c_int, c_int, _P],
 }
 _RESTYPE = {"cp2_error_string": c_char_p}
 

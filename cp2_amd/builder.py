@@ -192,8 +192,6 @@ class MODEL(nn.Module):
         if backbone_type != BackboneType.DEEPLABV3:
             raise NotImplementedError(f"{backbone_type = }: the U-Net backbones need segmentation_models_pytorch "
                                       "(out of scope of the MI355X hot path; SURVEY.md section 2.1)")
-        if negative_type != NegativeType.NONE:
-            raise NotImplementedError(f"{negative_type = }: experimental logit reshaping is a 'next' row (SURVEY 8f-4)")
         self.amp_dtype, self.channels_last, self.log_fn = amp_dtype, channels_last, log_fn
 
         self.encoder_q = build_segmentor(cfg.model, train_cfg=cfg.get("train_cfg"), test_cfg=cfg.get("test_cfg"))
@@ -222,6 +220,18 @@ class MODEL(nn.Module):
             assert self.temp_global == 0.2 and self.temp_local == 0.2, (self.temp_global, self.temp_local)
             if pretrain_type == PretrainType.DENSECL:
                 assert not (use_predictor or use_avgpool_global or use_symmetrical_loss) and lmbd_coordinate == 0
+            # forward_densecl never runs the segmentation head, nor the neck heads its flags do not select.  The
+            # reference lets DDP search for them every step (find_unused_parameters=True, main.py:456-460); here they
+            # are frozen up front -- the same training dynamics (a parameter without gradient is not touched by SGD,
+            # weight decay included) with no per-step graph walk, and DDP never waits for their buckets.
+            neck = self.encoder_q.neck
+            unused = [self.encoder_q.decode_head]
+            if not use_predictor:
+                unused += [neck.global_predictor, neck.local_predictor]
+            if use_avgpool_global:
+                unused += [neck.global_projector, neck.global_predictor]
+            for mod in unused:
+                mod.requires_grad_(False)
         for pq, pk in zip(self.encoder_q.parameters(), self.encoder_k.parameters()):
             pk.data.copy_(pq.data)
             pk.requires_grad = False
@@ -476,7 +486,8 @@ class MODEL(nn.Module):
         out = CF.cp2_loss_section(q, k, mask_a, mask_b, self.queue, temp_global=self.temp_global,
                                   temp_local=self.temp_local, lmbd_dense=self.lmbd_dense_loss,
                                   include_background=self.include_background, ids=ids, weights=weights,
-                                  want_quartiles=self.log_quartiles)
+                                  want_quartiles=self.log_quartiles, negative_type=self.negative_type.value,
+                                  negative_scale=self.negative_scale)
         self._dequeue_and_enqueue(out.k_pos)
         logs = {"train/loss_step": out.loss.detach(), "train/loss_ins_step": out.loss_instance,
                 "train/loss_dense_step": out.loss_dense, "train/acc_ins_step": out.acc1,

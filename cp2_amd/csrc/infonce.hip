@@ -792,7 +792,16 @@ struct DenseArgs {
     // statistics part[7][S][B*P] = {max, sum exp, colsum_a, possum, allsum, best value, best x}; dense_merge_kernel
     // folds them into the per-key outputs above
     int splits; float* part;
+    // NegativeType reshaping of the negative pairs' raw logits (builder.py:1332-1386): L -> 2 / (1 + exp(-scale (L - centre))) - 1
+    float neg_scale; const float* neg_center;    // centre per sample [B], or NULL = 0 (FIXED)
 };
+
+// value and derivative of the squashing function of the negative pairs
+__device__ __forceinline__ float neg_squash(float raw, float scale, float cen, float* dfd) {
+    const float sig = 1.f / (1.f + expf(-scale * (raw - cen)));
+    if (dfd) *dfd = 2.f * scale * sig * (1.f - sig);
+    return 2.f * sig - 1.f;
+}
 
 __device__ __forceinline__ float corr_weight(int64_t pa, int64_t pb, int64_t ra, int64_t rb, float wp, float wr, float wn) {
     // builder.py:1225-1243: pixel match -> w_pixel, else known-region match -> w_region, else 0; zeros become w_not
@@ -822,7 +831,7 @@ struct DenseLds {
 
 // owners = key pixels y (lane), others = query pixels x (LDS tile).  Column-wise softmax
 // statistics over x for every y, the masked column sums, and the logging sums.
-template <bool WEIGHTS>
+template <bool WEIGHTS, bool NEG = false>
 __global__ __launch_bounds__(DNT, 2) void dense_fwd_kernel(DenseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DenseLds& L = *reinterpret_cast<DenseLds*>(smem);
@@ -842,6 +851,8 @@ __global__ __launch_bounds__(DNT, 2) void dense_fwd_kernel(DenseArgs a) {
     if (WEIGHTS && y_ok) { pb = a.pix_b[(int64_t)n * P + y]; rb = a.reg_b[(int64_t)n * P + y]; }
     float m_run = -INFINITY, s_run = 0.f, a_run = 0.f, pos_run = 0.f, all_run = 0.f, best_v = -INFINITY;
     int best_x = 0;
+    const float mb_y = (NEG && y_ok) ? a.mask_b[(int64_t)n * P + y] : 0.f;
+    const float cen = (NEG && a.neg_center) ? a.neg_center[n] : 0.f;
     const bool vec_ok = (P % 4 == 0) && ((reinterpret_cast<uintptr_t>(qd) & 15u) == 0);
     const int xs = (((P + S - 1) / S + DKT - 1) / DKT) * DKT;     // this split's query pixels: [x_begin, x_end)
     const int x_begin = sp * xs, x_end = min(P, x_begin + xs);
@@ -875,7 +886,9 @@ __global__ __launch_bounds__(DNT, 2) void dense_fwd_kernel(DenseArgs a) {
                 if (a.logits_out && valid && y_ok) a.logits_out[((int64_t)n * P + x) * P + y] = raw;
                 float w = 1.f;
                 if (WEIGHTS) w = corr_weight(L.pid[xi], pb, L.rid[xi], rb, a.w_pixel, a.w_region, a.w_not);
-                const float v = raw * w * a.inv_t;
+                float rs = raw;                            // the logging sums below keep the raw score (stats come first, :1298)
+                if (NEG && (L.ma[xi] * mb_y) == 0.f) rs = neg_squash(raw, a.neg_scale, cen, nullptr);
+                const float v = rs * w * a.inv_t;
                 sv[reg] = valid ? v : -INFINITY;
                 if (valid) {
                     const float ma = L.ma[xi];
@@ -1017,7 +1030,7 @@ __global__ __launch_bounds__(64) void dense_batch_kernel(const float* __restrict
 // owners = query pixels x (lane), others = key pixels y (LDS tile).
 //   d loss_n / d Ls[x][y] = mb[y] (Sa softmax_x(Ls)[x][y] - ma[x]) / (Sa Sb),  Ls = L w / T
 //   g_dense[c][x] = grad_scale * sum_y kd[c][y] * (w/T) * dLs[x][y]
-template <bool WEIGHTS>
+template <bool WEIGHTS, bool NEG = false>
 __global__ __launch_bounds__(DNT, 2) void dense_bwd_kernel(DenseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DenseLds& L = *reinterpret_cast<DenseLds*>(smem);
@@ -1036,6 +1049,7 @@ __global__ __launch_bounds__(DNT, 2) void dense_bwd_kernel(DenseArgs a) {
     const float Sa = a.sample_scal[(int64_t)n * 8 + 0], Sb = a.sample_scal[(int64_t)n * 8 + 1];
     const float gs = a.grad_scale * a.inv_t / (Sa * Sb);
     const float ma = x_ok ? a.mask_a[(int64_t)n * P + x] : 0.f;
+    const float cen = (NEG && a.neg_center) ? a.neg_center[n] : 0.f;
     int64_t pa = -1, ra = 0;
     if (WEIGHTS && x_ok) { pa = a.pix_a[(int64_t)n * P + x]; ra = a.reg_a[(int64_t)n * P + x]; }
     f32x16 U[4];
@@ -1072,9 +1086,11 @@ __global__ __launch_bounds__(DNT, 2) void dense_bwd_kernel(DenseArgs a) {
                 const bool valid = (y0 + yi) < P;
                 float w = 1.f;
                 if (WEIGHTS) w = corr_weight(pa, L.pid[yi], ra, L.rid[yi], a.w_pixel, a.w_region, a.w_not);
-                const float ls = acc[reg] * w * a.inv_t;
+                float rs = acc[reg], dfd = 1.f;
+                if (NEG && (ma * L.ma[yi]) == 0.f) rs = neg_squash(acc[reg], a.neg_scale, cen, &dfd);
+                const float ls = rs * w * a.inv_t;
                 const float sm = __expf(ls - L.aux[yi]);
-                p[reg] = (valid && x_ok) ? gs * w * L.ma[yi] * (Sa * sm - ma) : 0.f;
+                p[reg] = (valid && x_ok) ? gs * w * dfd * L.ma[yi] * (Sa * sm - ma) : 0.f;
             }
             product2<DKP>(L.T, kk, p, U, r, h);
         }
@@ -1126,18 +1142,22 @@ CP2_API int cp2_dense_infonce_fwd(const float* q_dense, const float* k_dense, co
                                   const int64_t* reg_a, const int64_t* reg_b, float w_pixel, float w_region,
                                   float w_not, float temperature, float* lse, float* colsum_a, float* possum,
                                   float* allsum, float* colmax, int32_t* argx, float* sample_scal, float* batch_out,
-                                  float* logits_out, float* split_ws, int B, int C, int P, void* stream) {
+                                  float* logits_out, float* split_ws, int negative_mode, float negative_scale,
+                                  const float* negative_center, int B, int C, int P, void* stream) {
     int rc = dense_check(q_dense, k_dense, mask_a, mask_b, pix_a, pix_b, reg_a, reg_b, B, C, P, temperature);
     if (rc) return rc;
     if (!lse || !colsum_a || !possum || !allsum || !colmax || !argx || !sample_scal || !batch_out) return CP2_ERR_NULL;
     const int S = split_ws ? cp2_dense_num_splits(B, P) : 1;
     DenseArgs a{q_dense, k_dense, mask_a, mask_b, pix_a, pix_b, reg_a, reg_b, w_pixel, w_region, w_not,
                 1.0f / temperature, P, lse, colsum_a, possum, allsum, colmax, argx, logits_out, nullptr, 0.f, nullptr,
-                S, split_ws};
+                S, split_ws, negative_scale, negative_center};
     const dim3 grid(cp2_cdiv(P, 32 * DNW) * B * S);
     const size_t lds = sizeof(DenseLds);
-    if (pix_a) hipLaunchKernelGGL(dense_fwd_kernel<true>, grid, dim3(DNT), lds, cp2_stream(stream), a);
-    else hipLaunchKernelGGL(dense_fwd_kernel<false>, grid, dim3(DNT), lds, cp2_stream(stream), a);
+    if (negative_mode) {
+        if (pix_a) hipLaunchKernelGGL((dense_fwd_kernel<true, true>), grid, dim3(DNT), lds, cp2_stream(stream), a);
+        else hipLaunchKernelGGL((dense_fwd_kernel<false, true>), grid, dim3(DNT), lds, cp2_stream(stream), a);
+    } else if (pix_a) hipLaunchKernelGGL((dense_fwd_kernel<true, false>), grid, dim3(DNT), lds, cp2_stream(stream), a);
+    else hipLaunchKernelGGL((dense_fwd_kernel<false, false>), grid, dim3(DNT), lds, cp2_stream(stream), a);
     rc = cp2_launch_status();
     if (rc) return rc;
     if (S > 1) {
@@ -1157,7 +1177,8 @@ CP2_API int cp2_dense_infonce_bwd(const float* q_dense, const float* k_dense, co
                                   const float* mask_b, const int64_t* pix_a, const int64_t* pix_b,
                                   const int64_t* reg_a, const int64_t* reg_b, float w_pixel, float w_region,
                                   float w_not, float temperature, const float* lse, const float* sample_scal,
-                                  float grad_scale, float* g_dense, float* split_ws, int B, int C, int P,
+                                  float grad_scale, float* g_dense, float* split_ws, int negative_mode,
+                                  float negative_scale, const float* negative_center, int B, int C, int P,
                                   void* stream) {
     int rc = dense_check(q_dense, k_dense, mask_a, mask_b, pix_a, pix_b, reg_a, reg_b, B, C, P, temperature);
     if (rc) return rc;
@@ -1165,11 +1186,14 @@ CP2_API int cp2_dense_infonce_bwd(const float* q_dense, const float* k_dense, co
     const int S = split_ws ? cp2_dense_num_splits(B, P) : 1;
     DenseArgs a{q_dense, k_dense, mask_a, mask_b, pix_a, pix_b, reg_a, reg_b, w_pixel, w_region, w_not,
                 1.0f / temperature, P, const_cast<float*>(lse), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                sample_scal, grad_scale, g_dense, S, split_ws};
+                sample_scal, grad_scale, g_dense, S, split_ws, negative_scale, negative_center};
     const dim3 grid(cp2_cdiv(P, 32 * DNW) * B * S);
     const size_t lds = sizeof(DenseLds);
-    if (pix_a) hipLaunchKernelGGL(dense_bwd_kernel<true>, grid, dim3(DNT), lds, cp2_stream(stream), a);
-    else hipLaunchKernelGGL(dense_bwd_kernel<false>, grid, dim3(DNT), lds, cp2_stream(stream), a);
+    if (negative_mode) {
+        if (pix_a) hipLaunchKernelGGL((dense_bwd_kernel<true, true>), grid, dim3(DNT), lds, cp2_stream(stream), a);
+        else hipLaunchKernelGGL((dense_bwd_kernel<false, true>), grid, dim3(DNT), lds, cp2_stream(stream), a);
+    } else if (pix_a) hipLaunchKernelGGL((dense_bwd_kernel<true, false>), grid, dim3(DNT), lds, cp2_stream(stream), a);
+    else hipLaunchKernelGGL((dense_bwd_kernel<false, false>), grid, dim3(DNT), lds, cp2_stream(stream), a);
     rc = cp2_launch_status();
     if (rc || S == 1) return rc;
     const int64_t n = (int64_t)B * CH * P;

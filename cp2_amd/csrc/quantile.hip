@@ -49,7 +49,20 @@ __device__ __forceinline__ unsigned block_scan_incl(unsigned v, unsigned* wtot) 
     return incl + base;
 }
 
-__global__ __launch_bounds__(QT) void quantiles_kernel(QuantArgs a) {
+// Up to QJOBS independent problems in ONE launch (the three logging statistics of a CP2 step: queue-logit rows,
+// positive and negative dense pairs): a workgroup handles one row of one job, so 96 CUs work for one launch duration
+// instead of 32 CUs three times in a row.
+constexpr int QJOBS = 4;
+struct QuantJobs {
+    QuantArgs job[QJOBS];
+    int first_row[QJOBS + 1];                              // workgroup b belongs to job j with first_row[j] <= b < first_row[j+1]
+};
+
+__global__ __launch_bounds__(QT) void quantiles_kernel(QuantJobs jobs) {
+    int jsel = 0;
+#pragma unroll
+    for (int j = 1; j < QJOBS; ++j) jsel += ((int)blockIdx.x >= jobs.first_row[j]) ? 1 : 0;
+    const QuantArgs& a = jobs.job[jsel];
     extern __shared__ __attribute__((aligned(16))) unsigned char q_smem[];
     __shared__ unsigned hist0[QB0];
     __shared__ unsigned hist[QMAX][QB1];
@@ -57,7 +70,7 @@ __global__ __launch_bounds__(QT) void quantiles_kernel(QuantArgs a) {
     __shared__ unsigned sh_prefix[QMAX], sh_k[QMAX], sh_min[QMAX], sh_next[QMAX], sh_n;
     float* lma = reinterpret_cast<float*>(q_smem);
     float* lmb = lma + (a.want >= 0 ? a.P : 0);
-    const int r = blockIdx.x, tid = threadIdx.x, NQ = a.NQ;
+    const int r = (int)blockIdx.x - jobs.first_row[jsel], tid = threadIdx.x, NQ = a.NQ;
     const float* row = a.x + (int64_t)r * a.s_row;
     const bool masked = a.want >= 0;
     if (masked) {
@@ -75,20 +88,28 @@ __global__ __launch_bounds__(QT) void quantiles_kernel(QuantArgs a) {
 #define CP2_Q_FOREACH(BODY)                                                                              \
     if (vec) {                                                                                           \
         const int n4 = (a.N + 3) >> 2;                                                                   \
-        for (int i4 = tid; i4 < n4; i4 += QT) {                                                          \
-            const int i0 = i4 * 4;                                                                       \
-            float vv[4];                                                                                 \
-            if (i0 + 3 < a.N) {                                                                          \
-                const float4 t4 = *reinterpret_cast<const float4*>(row + i0);                            \
-                vv[0] = t4.x; vv[1] = t4.y; vv[2] = t4.z; vv[3] = t4.w;                                  \
-            } else {                                                                                     \
-                _Pragma("unroll") for (int u = 0; u < 4; ++u) vv[u] = (i0 + u < a.N) ? row[i0 + u] : NAN; \
+        for (int j4 = tid; j4 < n4; j4 += 4 * QT) {                                                      \
+            float4 t4[4];                                                                                \
+            _Pragma("unroll") for (int g = 0; g < 4; ++g) {      /* four 16-byte loads in flight */       \
+                const int i0 = (j4 + g * QT) * 4;                                                        \
+                if (i0 + 3 < a.N) {                                                                      \
+                    t4[g] = *reinterpret_cast<const float4*>(row + i0);                                  \
+                } else {                                                                                 \
+                    t4[g].x = (i0 + 0 < a.N) ? row[i0 + 0] : NAN;                                        \
+                    t4[g].y = (i0 + 1 < a.N) ? row[i0 + 1] : NAN;                                        \
+                    t4[g].z = (i0 + 2 < a.N) ? row[i0 + 2] : NAN;                                        \
+                    t4[g].w = NAN;                                                                       \
+                }                                                                                        \
             }                                                                                            \
-            int x_ = masked ? i0 / a.P : 0, y_ = masked ? i0 % a.P : 0;                                  \
-            _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                              \
-                const float v = vv[u];                                                                   \
-                if (keep_at(x_, y_, v)) { BODY }                                                         \
-                if (masked && ++y_ >= a.P) { y_ = 0; ++x_; }                                             \
+            _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                              \
+                const int i0 = (j4 + g * QT) * 4;                                                        \
+                const float vv[4] = {t4[g].x, t4[g].y, t4[g].z, t4[g].w};                                \
+                int x_ = masked ? i0 / a.P : 0, y_ = masked ? i0 % a.P : 0;                              \
+                _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                          \
+                    const float v = vv[u];                                                               \
+                    if (keep_at(x_, y_, v)) { BODY }                                                     \
+                    if (masked && ++y_ >= a.P) { y_ = 0; ++x_; }                                         \
+                }                                                                                        \
             }                                                                                            \
         }                                                                                                \
     } else {                                                                                             \
@@ -196,21 +217,53 @@ __global__ __launch_bounds__(QT) void quantiles_kernel(QuantArgs a) {
 #undef CP2_Q_FOREACH
 }
 
-CP2_API int cp2_masked_quantiles(const float* x, int64_t stride_row, int64_t stride_elem, int R, int N,
-                                 const float* mask_a, const float* mask_b, int P, int want, const float* q, int NQ,
-                                 float* out, void* stream) {
-    if (!x || !q || !out) return CP2_ERR_NULL;
-    if (R <= 0 || N <= 0 || NQ <= 0) return CP2_ERR_SHAPE;
-    if (NQ > QMAX) return CP2_ERR_UNSUPPORTED;
-    if (want >= 0 && (!mask_a || !mask_b || P <= 0 || (int64_t)P * P != N)) return CP2_ERR_SHAPE;
-    if (want >= 0 && P > 8192) return CP2_ERR_UNSUPPORTED;
-    QuantArgs a{x, stride_row, stride_elem, N, mask_a, mask_b, P, want, q, NQ, out, R};
-    const size_t lds = want >= 0 ? 2 * (size_t)P * sizeof(float) : 0;
-    if (lds > 32768) {
+static int quant_check(const QuantArgs& a) {
+    if (!a.x || !a.q || !a.out) return CP2_ERR_NULL;
+    if (a.R <= 0 || a.N <= 0 || a.NQ <= 0) return CP2_ERR_SHAPE;
+    if (a.NQ > QMAX) return CP2_ERR_UNSUPPORTED;
+    if (a.want >= 0 && (!a.mask_a || !a.mask_b || a.P <= 0 || (int64_t)a.P * a.P != a.N)) return CP2_ERR_SHAPE;
+    if (a.want >= 0 && a.P > 8192) return CP2_ERR_UNSUPPORTED;
+    return CP2_OK;
+}
+
+static int quant_launch(const QuantJobs& jobs, int njobs, hipStream_t stream) {
+    size_t lds = 0;
+    for (int j = 0; j < njobs; ++j) {
+        int rc = quant_check(jobs.job[j]);
+        if (rc) return rc;
+        const size_t l = jobs.job[j].want >= 0 ? 2 * (size_t)jobs.job[j].P * sizeof(float) : 0;
+        if (l > lds) lds = l;
+    }
+    if (lds > 16384) {
         hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(quantiles_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e_ != hipSuccess) return (int)e_;
     }
-    hipLaunchKernelGGL(quantiles_kernel, dim3(R), dim3(QT), lds, cp2_stream(stream), a);
+    hipLaunchKernelGGL(quantiles_kernel, dim3(jobs.first_row[njobs]), dim3(QT), lds, stream, jobs);
     return cp2_launch_status();
+}
+
+CP2_API int cp2_masked_quantiles(const float* x, int64_t stride_row, int64_t stride_elem, int R, int N,
+                                 const float* mask_a, const float* mask_b, int P, int want, const float* q, int NQ,
+                                 float* out, void* stream) {
+    QuantJobs jobs{};
+    jobs.job[0] = QuantArgs{x, stride_row, stride_elem, N, mask_a, mask_b, P, want, q, NQ, out, R};
+    for (int j = 1; j <= QJOBS; ++j) jobs.first_row[j] = R > 0 ? R : 0;
+    return quant_launch(jobs, 1, cp2_stream(stream));
+}
+
+CP2_API int cp2_masked_quantiles_multi(int njobs, const float* const* x, const int64_t* stride_row, const int64_t* stride_elem,
+                                       const int* R, const int* N, const float* const* mask_a, const float* const* mask_b,
+                                       const int* P, const int* want, const float* q, int NQ, float* const* out, void* stream) {
+    if (njobs <= 0 || njobs > QJOBS) return CP2_ERR_UNSUPPORTED;
+    if (!x || !stride_row || !stride_elem || !R || !N || !mask_a || !mask_b || !P || !want || !out) return CP2_ERR_NULL;
+    QuantJobs jobs{};
+    int rows = 0;
+    for (int j = 0; j < njobs; ++j) {
+        jobs.job[j] = QuantArgs{x[j], stride_row[j], stride_elem[j], N[j], mask_a[j], mask_b[j], P[j], want[j], q, NQ, out[j], R[j]};
+        jobs.first_row[j] = rows;
+        rows += R[j] > 0 ? R[j] : 0;
+    }
+    for (int j = njobs; j <= QJOBS; ++j) jobs.first_row[j] = rows;
+    return quant_launch(jobs, njobs, cp2_stream(stream));
 }

@@ -16,6 +16,9 @@ import torch
 from . import ops
 
 
+NEG_NONE, NEG_FIXED, NEG_AVERAGE, NEG_MEDIAN, NEG_HARD = 0, 1, 2, 3, 4     # builder.NegativeType values
+
+
 @dataclass
 class CP2LossOutputs:
     loss: torch.Tensor               # scalar, differentiable w.r.t. q_feat
@@ -39,7 +42,7 @@ class CP2LossOutputs:
 class _CP2LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q_feat, k_feat, mask_a, mask_b, queue, cfg):
-        (temp_global, temp_local, lmbd_dense, include_background, ids, weights, want_lneg, want_quart) = cfg
+        (temp_global, temp_local, lmbd_dense, include_background, ids, weights, want_lneg, want_quart, negative) = cfg
         want_lneg = want_lneg or want_quart
         B = q_feat.shape[0]
         need_grad = q_feat.requires_grad
@@ -52,10 +55,27 @@ class _CP2LossFn(torch.autograd.Function):
         C = q_pos.shape[1]
         ins = ops.rowkey_infonce(q_pos, (1, C, 0, 1), B, queue, ext, temp_global,
                                  grad_scale=(1.0 / B) if need_grad else None, want_lneg=want_lneg, lneg_row_major=True)
-        den = ops.dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temp_local, ids, weights, want_logits=want_quart)
+        # NegativeType (reference builder.py:1332-1386): the negative pairs' logits are squashed around 0 (FIXED) or
+        # around the sample's mean / median negative score, which needs one un-reshaped pass first; HARD edits a copy
+        # in the reference, i.e. it is the identity.
+        neg = None
+        ntype, nscale = negative
+        if ntype == NEG_FIXED:
+            neg = (nscale, None)
+        elif ntype in (NEG_AVERAGE, NEG_MEDIAN):
+            pre = ops.dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temp_local, ids, weights,
+                                        want_logits=(ntype == NEG_MEDIAN))
+            if ntype == NEG_AVERAGE:
+                centre = pre.sample_scal[:, 4].contiguous()
+            else:
+                centre = ops.masked_quantiles(pre.logits, P * P, 1, B, P * P, mask_a=mask_a, mask_b=mask_b, want=0)[1].contiguous()
+            neg = (nscale, centre)
+        den = ops.dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temp_local, ids, weights, want_logits=want_quart,
+                                    negative=neg)
         loss = ins.loss + den.loss * lmbd_dense
         if need_grad:
-            g_dense = ops.dense_infonce_bwd(q_dense, k_dense, mask_a, mask_b, temp_local, den, lmbd_dense / B, ids, weights)
+            g_dense = ops.dense_infonce_bwd(q_dense, k_dense, mask_a, mask_b, temp_local, den, lmbd_dense / B, ids, weights,
+                                            negative=neg)
             if ne == 1:
                 dE = torch.zeros((B, 3), dtype=torch.float32, device=q_feat.device)
                 dE[:, :1] = ins.dE
@@ -71,9 +91,10 @@ class _CP2LossFn(torch.autograd.Function):
             outs = outs + (ins.lneg,)
         if want_quart:
             K = queue.shape[1]
-            outs = outs + (ops.masked_quantiles(den.logits, P * P, 1, B, P * P, mask_a=mask_a, mask_b=mask_b, want=1),
-                           ops.masked_quantiles(den.logits, P * P, 1, B, P * P, mask_a=mask_a, mask_b=mask_b, want=0),
-                           ops.masked_quantiles(ins.lneg, K, 1, B, K), ins.lneg.mean(1))
+            dense = dict(x=den.logits, stride_row=P * P, stride_elem=1, R=B, N=P * P, mask_a=mask_a, mask_b=mask_b)
+            qs = ops.masked_quantiles_multi([dict(dense, want=1), dict(dense, want=0),       # one launch for all three
+                                             dict(x=ins.lneg, stride_row=K, stride_elem=1, R=B, N=K)])
+            outs = outs + (qs[0], qs[1], qs[2], ins.lneg.mean(1))
         ctx.mark_non_differentiable(*outs[1:])
         return outs
 
@@ -87,15 +108,17 @@ def cp2_loss_section(q_feat: torch.Tensor, k_feat: torch.Tensor, mask_a: torch.T
                      queue: torch.Tensor, *, temp_global: float = 0.2, temp_local: float = 1.0,
                      lmbd_dense: float = 0.2, include_background: bool = False, ids=None,
                      weights: Tuple[float, float, float] = (1.0, 1.0, 1.0), want_lneg: bool = False,
-                     want_quartiles: bool = False) -> CP2LossOutputs:
+                     want_quartiles: bool = False, negative_type: int = 0, negative_scale: float = 2.0) -> CP2LossOutputs:
     """q_feat / k_feat: encoder outputs [B,128,h,w] (NCHW or channels-last, fp32; k already
     un-shuffled, no grad); mask_a / mask_b: [B,P] down-sampled foreground masks; queue [128,K].
     ids = (pixel_ids_a, pixel_ids_b, region_ids_a, region_ids_b) int64 [B,P] when the
     correspondence weights are not all one (reference builder.py:1225-1243)."""
     if ids is not None and tuple(float(w) for w in weights) == (1.0, 1.0, 1.0):
         ids = None                                   # all weights one: the predicate is never needed
+    if int(negative_type) not in (NEG_NONE, NEG_FIXED, NEG_AVERAGE, NEG_MEDIAN, NEG_HARD):
+        raise ValueError(f"negative_type {negative_type!r}")
     cfg = (float(temp_global), float(temp_local), float(lmbd_dense), bool(include_background), ids,
-           tuple(float(w) for w in weights), bool(want_lneg), bool(want_quartiles))
+           tuple(float(w) for w in weights), bool(want_lneg), bool(want_quartiles), (int(negative_type), float(negative_scale)))
     outs = _CP2LossFn.apply(q_feat, k_feat.detach(), mask_a, mask_b, queue, cfg)
     res = CP2LossOutputs(*outs[:10])
     i = 10

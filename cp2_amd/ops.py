@@ -408,9 +408,19 @@ def _ids4(ids):
             _dev(ra, "region_ids_a", torch.int64), _dev(rb, "region_ids_b", torch.int64))
 
 
+def _negative(negative):
+    """negative = None | (scale, centre): centre None (FIXED, builder.py:1332-1338) or a device float[B] tensor
+    (AVERAGE / MEDIAN, :1340-1373) -> (mode, scale, centre pointer)."""
+    if negative is None:
+        return 0, 0.0, None
+    scale, centre = negative
+    return 1, float(scale), _opt(centre, "negative_center", torch.float32)
+
+
 def dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temperature: float, ids=None,
-                      weights=(1.0, 1.0, 1.0), want_logits: bool = False, split: bool = True) -> DenseResult:
+                      weights=(1.0, 1.0, 1.0), want_logits: bool = False, split: bool = True, negative=None) -> DenseResult:
     lib = _lib.load()
+    nmode, nscale, ncen = _negative(negative)
     B, C, P = q_dense.shape
     dev = q_dense.device
     f = lambda: torch.empty((B, P), dtype=torch.float32, device=dev)  # noqa: E731
@@ -429,15 +439,16 @@ def dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temperature: float, ids=
                                    float(temperature), res.lse.data_ptr(), colsum.data_ptr(), possum.data_ptr(),
                                    allsum.data_ptr(), res.colmax.data_ptr(), res.argx.data_ptr(),
                                    res.sample_scal.data_ptr(), batch.data_ptr(), _opt(res.logits, "logits"),
-                                   split_ws.data_ptr() if split_ws is not None else None, B, C, P, _stream())
+                                   split_ws.data_ptr() if split_ws is not None else None, nmode, nscale, ncen, B, C, P, _stream())
     _lib.check(rc, "cp2_dense_infonce_fwd")
     res.loss, res.acc = batch[0], batch[1]
     return res
 
 
 def dense_infonce_bwd(q_dense, k_dense, mask_a, mask_b, temperature: float, fwd: DenseResult, grad_scale: float,
-                      ids=None, weights=(1.0, 1.0, 1.0), split: bool = True) -> torch.Tensor:
+                      ids=None, weights=(1.0, 1.0, 1.0), split: bool = True, negative=None) -> torch.Tensor:
     lib = _lib.load()
+    nmode, nscale, ncen = _negative(negative)
     B, C, P = q_dense.shape
     g = torch.empty_like(q_dense)
     pa, pb, ra, rb = _ids4(ids)
@@ -447,7 +458,7 @@ def dense_infonce_bwd(q_dense, k_dense, mask_a, mask_b, temperature: float, fwd:
                                    _dev(mask_b, "mask_b"), pa, pb, ra, rb, float(weights[0]), float(weights[1]),
                                    float(weights[2]), float(temperature), fwd.lse.data_ptr(), fwd.sample_scal.data_ptr(),
                                    float(grad_scale), g.data_ptr(), split_ws.data_ptr() if split_ws is not None else None,
-                                   B, C, P, _stream())
+                                   nmode, nscale, ncen, B, C, P, _stream())
     _lib.check(rc, "cp2_dense_infonce_bwd")
     return g
 
@@ -480,6 +491,32 @@ def masked_quantiles(x: torch.Tensor, stride_row: int, stride_elem: int, R: int,
                                   out.data_ptr(), _stream())
     _lib.check(rc, "cp2_masked_quantiles")
     return out
+
+
+def masked_quantiles_multi(jobs, q: Optional[torch.Tensor] = None):
+    """Several masked_quantiles problems in one launch.  jobs: list of dicts with the keyword arguments of
+    masked_quantiles (x, stride_row, stride_elem, R, N, mask_a, mask_b, want); returns the list of outputs."""
+    import ctypes
+    lib = _lib.load()
+    n = len(jobs)
+    dev = jobs[0]["x"].device
+    if q is None:
+        q = _quartile_tensor(dev)
+    outs = [torch.empty((q.numel(), j["R"]), dtype=torch.float32, device=dev) for j in jobs]
+    P_ = ctypes.c_void_p * n
+    I64, I32 = ctypes.c_int64 * n, ctypes.c_int * n
+    for j in jobs:
+        if not j["x"].is_cuda or j["x"].dtype != torch.float32:
+            raise _lib.Cp2LibraryError("masked_quantiles_multi: x must be a float32 GPU tensor")
+    ma = [_opt(j.get("mask_a"), "mask_a", torch.float32) for j in jobs]
+    mb = [_opt(j.get("mask_b"), "mask_b", torch.float32) for j in jobs]
+    rc = lib.cp2_masked_quantiles_multi(
+        n, P_(*[j["x"].data_ptr() for j in jobs]), I64(*[j["stride_row"] for j in jobs]), I64(*[j["stride_elem"] for j in jobs]),
+        I32(*[j["R"] for j in jobs]), I32(*[j["N"] for j in jobs]), P_(*ma), P_(*mb),
+        I32(*[(j["mask_a"].shape[1] if j.get("mask_a") is not None else 0) for j in jobs]),
+        I32(*[j.get("want", -1) for j in jobs]), _dev(q, "q", torch.float32), q.numel(), P_(*[o.data_ptr() for o in outs]), _stream())
+    _lib.check(rc, "cp2_masked_quantiles_multi")
+    return outs
 
 
 # ---------------------------------------------------------------- encoder fast path: fused BatchNorm

@@ -156,13 +156,18 @@ int cp2_rowkey_infonce_finalize(const float* part_m, const float* part_s, const 
  * logits_out: NULL, or [B,P,P] to also receive the raw logits q.k (only for the logging quantiles).   C = 128.
  * split_ws: NULL (one workgroup per (sample, 128-key tile) walks all query pixels), or float[7 * S * B * P] with
  * S = cp2_dense_num_splits(B, P): S workgroups share the walk and a merge kernel folds their partial statistics, so
- * small B*P still fills the chip. */
+ * small B*P still fills the chip.
+ * negative_mode != 0 (reference NegativeType FIXED / AVERAGE / MEDIAN, builder.py:1332-1386): the raw logit L of every
+ * NEGATIVE pair (mask_a[x]*mask_b[y] == 0) enters the loss as 2 / (1 + exp(-negative_scale * (L - centre))) - 1 with
+ * centre = negative_center[n] (device float[B]: the sample's mean or median negative score, taken from a first
+ * un-reshaped pass) or 0 when negative_center is NULL (FIXED); the logging sums always use the raw scores. */
 int cp2_dense_num_splits(int B, int P);
 int cp2_dense_infonce_fwd(const float* q_dense, const float* k_dense, const float* mask_a, const float* mask_b,
                           const int64_t* pix_a, const int64_t* pix_b, const int64_t* reg_a, const int64_t* reg_b,
                           float w_pixel, float w_region, float w_not, float temperature, float* lse,
                           float* colsum_a, float* possum, float* allsum, float* colmax, int32_t* argx,
-                          float* sample_scal, float* batch_out, float* logits_out, float* split_ws, int B, int C,
+                          float* sample_scal, float* batch_out, float* logits_out, float* split_ws,
+                          int negative_mode, float negative_scale, const float* negative_center, int B, int C,
                           int P, void* stream);
 /* g_dense [B,C,P] = grad_scale * d (sum_n loss_n) / d q_dense, recomputing the logits tile by tile.
  * split_ws: NULL, or float[S * B * C * P] with S = cp2_dense_num_splits(B, P): the key-pixel range is shared by S
@@ -170,7 +175,8 @@ int cp2_dense_infonce_fwd(const float* q_dense, const float* k_dense, const floa
 int cp2_dense_infonce_bwd(const float* q_dense, const float* k_dense, const float* mask_a, const float* mask_b,
                           const int64_t* pix_a, const int64_t* pix_b, const int64_t* reg_a, const int64_t* reg_b,
                           float w_pixel, float w_region, float w_not, float temperature, const float* lse,
-                          const float* sample_scal, float grad_scale, float* g_dense, float* split_ws, int B, int C,
+                          const float* sample_scal, float grad_scale, float* g_dense, float* split_ws,
+                          int negative_mode, float negative_scale, const float* negative_center, int B, int C,
                           int P, void* stream);
 
 /* ---- a15: logging quantiles without a sort ---------------- tools/correlation_mapping.py:16-53, builder.py:1399-1406
@@ -181,6 +187,11 @@ int cp2_dense_infonce_bwd(const float* q_dense, const float* k_dense, const floa
 int cp2_masked_quantiles(const float* x, int64_t stride_row, int64_t stride_elem, int R, int N,
                          const float* mask_a, const float* mask_b, int P, int want, const float* q, int NQ,
                          float* out, void* stream);
+/* Up to 4 such problems in ONE launch (one workgroup per row of every job; NQ <= 4 quantiles q shared by all jobs).
+ * Every argument of cp2_masked_quantiles becomes a HOST array of njobs entries (device pointers inside). */
+int cp2_masked_quantiles_multi(int njobs, const float* const* x, const int64_t* stride_row, const int64_t* stride_elem,
+                               const int* R, const int* N, const float* const* mask_a, const float* const* mask_b,
+                               const int* P, const int* want, const float* q, int NQ, float* const* out, void* stream);
 
 /* ---- optimizer step of the query encoder on the flat parameter buffer ---------------- main.py:467-477, :640-642
  * torch.optim.SGD(momentum, weight_decay) (dampening 0, no Nesterov), bit-identical to torch's default multi-tensor

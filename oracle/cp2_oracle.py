@@ -167,6 +167,30 @@ def dense_infonce(logits_dense, mask_a, mask_b, temp_local=1.0, weights=None):
 
 
 # --------------------------------------------------------------------------
+# f4: NegativeType reshaping of the negative dense logits   builder.py:1332-1386
+# --------------------------------------------------------------------------
+NEG_NONE, NEG_FIXED, NEG_AVERAGE, NEG_MEDIAN, NEG_HARD = 0, 1, 2, 3, 4
+
+
+def reshape_negatives(logits_dense, labels_dense, negative_type=NEG_NONE, negative_scale=2.0, stats=None):
+    """Raw dense logits (n, x, y) -> logits with the NEGATIVE pairs (label 0) squashed through
+    2 / (1 + exp(-scale * (L - centre))) - 1, centre = 0 (FIXED), the sample's mean negative score (AVERAGE) or its
+    median negative score (MEDIAN); both centres are detached statistics of the raw logits (builder.py:1298-1300).
+    HARD multiplies a COPY of the selected negatives (chained advanced indexing, builder.py:1377-1381), so the
+    logits the loss sees are unchanged: it is the identity, like NONE."""
+    if negative_type in (NEG_NONE, NEG_HARD):
+        return logits_dense
+    n = logits_dense.shape[0]
+    if negative_type == NEG_FIXED:
+        centre = torch.zeros(n)
+    else:
+        st = stats if stats is not None else dense_loss_stats(logits_dense.detach(), labels_dense)
+        centre = st["negative"]["average"] if negative_type == NEG_AVERAGE else st["negative"]["quartiles"][1]
+    squashed = 2.0 / (1.0 + torch.exp((logits_dense - centre.detach().reshape(n, 1, 1)) * (-negative_scale))) - 1.0
+    return torch.where(labels_dense.bool(), logits_dense, squashed)
+
+
+# --------------------------------------------------------------------------
 # a10: instance InfoNCE against the queue    builder.py:1395-1397,1414-1428
 # --------------------------------------------------------------------------
 def instance_infonce(q_pos, k_pos, queue, temp_global=0.2, q_neg=None, k_neg=None,
@@ -225,13 +249,18 @@ def dense_argmax_accuracy(logits_dense_scaled, mask_a, mask_b):
 def cp2_loss_section(q_feat, k_feat, bg0, bg1, pixel_ids_a, pixel_ids_b, region_ids_a,
                      region_ids_b, queue, *, output_stride, temp_global=0.2, temp_local=1.0,
                      lmbd_dense=0.2, include_background=False,
-                     w_pixel=1, w_region=1, w_not=1, with_stats=False):
+                     w_pixel=1, w_region=1, w_not=1, with_stats=False,
+                     negative_type=NEG_NONE, negative_scale=2.0, masks_and_ids=None):
     """Everything forward_cp2 computes from encoder outputs to the loss.
-    q_feat/k_feat: (b, C, h', w') encoder outputs (k already un-shuffled)."""
-    mask_a = strided_gather(torch.eq(bg0[:, 0], 0).float(), output_stride)
-    mask_b = strided_gather(torch.eq(bg1[:, 0], 0).float(), output_stride)
-    pa, pb = strided_gather(pixel_ids_a, output_stride), strided_gather(pixel_ids_b, output_stride)
-    ra, rb = strided_gather(region_ids_a, output_stride), strided_gather(region_ids_b, output_stride)
+    q_feat/k_feat: (b, C, h', w') encoder outputs (k already un-shuffled).
+    masks_and_ids = (mask_a, mask_b, pa, pb, ra, rb) already down-sampled replaces bg*/ids (encoder-free fixtures)."""
+    if masks_and_ids is not None:
+        mask_a, mask_b, pa, pb, ra, rb = masks_and_ids
+    else:
+        mask_a = strided_gather(torch.eq(bg0[:, 0], 0).float(), output_stride)
+        mask_b = strided_gather(torch.eq(bg1[:, 0], 0).float(), output_stride)
+        pa, pb = strided_gather(pixel_ids_a, output_stride), strided_gather(pixel_ids_b, output_stride)
+        ra, rb = strided_gather(region_ids_a, output_stride), strided_gather(region_ids_b, output_stride)
     pix = masked_correlation_map(pa, pb, mask_a, mask_b)
     reg = masked_correlation_map(ra, rb, mask_a, mask_b)
     w = corr_weights(pix["corr_map"], reg["corr_map"], ra, rb, w_pixel, w_region, w_not)
@@ -243,17 +272,18 @@ def cp2_loss_section(q_feat, k_feat, bg0, bg1, pixel_ids_a, pixel_ids_b, region_
     raw = dense_logits(q_dense, k_dense)
     loss_ins, logits_moco, l_pos, l_neg = instance_infonce(
         q_pos, k_pos, queue, temp_global, q_neg, k_neg, include_background)
-    loss_den, loss_den_per_sample, lg_scaled = dense_infonce(raw, fma, fmb, temp_local, w)
+    labels = fma[:, :, None] * fmb[:, None, :]
+    reshaped = reshape_negatives(raw, labels, negative_type, negative_scale)      # identity unless a NegativeType is set
+    loss_den, loss_den_per_sample, lg_scaled = dense_infonce(reshaped, fma, fmb, temp_local, w)
     loss = loss_ins + loss_den * lmbd_dense
     out = dict(mask_a=fma, mask_b=fmb, pixel_ids_a=pa, pixel_ids_b=pb, region_ids_a=ra, region_ids_b=rb,
                iou=reg["iou"], iou_masked=reg["iou_masked"], pixel_iou=pix["iou"],
                pixel_iou_masked=pix["iou_masked"], corr_weights=w,
                q_dense=q_dense, k_dense=k_dense, q_pos=q_pos, k_pos=k_pos, q_neg=q_neg, k_neg=k_neg,
-               logits_dense_raw=raw, logits_moco=logits_moco, l_pos=l_pos, l_neg=l_neg,
+               logits_dense_raw=raw, logits_dense_reshaped=reshaped, logits_dense_scaled=lg_scaled, logits_moco=logits_moco, l_pos=l_pos, l_neg=l_neg,
                loss_instance=loss_ins, loss_dense=loss_den, loss_dense_per_sample=loss_den_per_sample,
                loss=loss)
     if with_stats:
-        labels = fma[:, :, None] * fmb[:, None, :]
         out["dense_stats"] = dense_loss_stats(raw.detach(), labels)
         out["instance_neg_mean"], out["instance_neg_quartiles"] = instance_stats(l_neg.detach())
         tgt = torch.zeros(b, dtype=torch.long)

@@ -116,14 +116,15 @@ def blank_model(K, dim=128, stride=16, **kw):
     m.lmbd_dense_loss = kw.get("lmbd_dense", 0.2)
     m.device, m.rank, m.epoch = "cpu", 1, 0
     m.contrastive_head = ref.ContrastiveHead()
-    m.use_predictor = m.use_avgpool_global = m.use_symmetrical_loss = False
+    m.use_predictor, m.use_avgpool_global = kw.get("use_predictor", False), kw.get("use_avgpool_global", False)
+    m.use_symmetrical_loss = kw.get("use_symmetrical_loss", False)
     m.lmbd_coordinate = kw.get("lmbd_coordinate", 0)
     m.mapping_type = kw.get("mapping_type", ref.MappingType.CP2)
     m.lmbd_pixel_corr_weight = kw.get("w_pixel", 1)
     m.lmbd_region_corr_weight = kw.get("w_region", 1)
     m.lmbd_not_corr_weight = kw.get("w_not", 1)
     m.pretrain_type = kw.get("pretrain_type", PretrainType.CP2)
-    m.negative_type, m.negative_scale = ref.NegativeType.NONE, 2
+    m.negative_type, m.negative_scale = kw.get("negative_type", ref.NegativeType.NONE), kw.get("negative_scale", 2)
     m.backbone_type = ref.BackboneType.DEEPLABV3
     m.output_stride = stride
     m.backbone_output_stride = kw.get("backbone_stride", 32)
@@ -182,7 +183,7 @@ CP2_KEEP = ("mask_a", "mask_b", "pixel_ids_a", "pixel_ids_b", "region_ids_a", "r
             "cross_image_variance_source", "cross_image_variance_target", "idx_unshuffle")
 
 
-def run_cp2_case(name, b, h, w, K, stride, seed, ptr0=0, **kw):
+def run_cp2_case(name, b, h, w, K, stride, seed, ptr0=0, slim=False, **kw):
     torch.manual_seed(seed)
     gen = torch.Generator().manual_seed(seed)
     m = blank_model(K, stride=stride, **kw)
@@ -202,7 +203,11 @@ def run_cp2_case(name, b, h, w, K, stride, seed, ptr0=0, **kw):
         loss = m.forward_cp2(visualize=False, step=0, new_epoch=False, **inp)
     loss.backward()
     loc = cap.locals
-    for k in CP2_KEEP:
+    if slim:     # experimental-variant fixtures: encoder outputs in, losses / gradient / reshaped logits out
+        rec = {k: v for k, v in rec.items() if k in ("queue_before", "ptr_before")}
+    for k in (("mask_a", "mask_b", "pixel_ids_a", "pixel_ids_b", "region_ids_a", "region_ids_b", "corr_weights",
+               "_logits_dense", "logits_dense", "l_pos", "loss_instance", "loss_dense", "loss",
+               "acc_dense", "idx_unshuffle", "negative_scores_average") if slim else CP2_KEEP):
         v = loc[k]
         rec[k] = np_(torch.stack(list(v)) if isinstance(v, (tuple, list)) else v)
     stats = loc["contrast_stats"]
@@ -224,6 +229,7 @@ def run_cp2_case(name, b, h, w, K, stride, seed, ptr0=0, **kw):
     rec["cfg"] = np.array([b, h, w, K, stride, int(m.include_background)], dtype=np.int64)
     rec["cfg_f"] = np.array([m.temp_global, m.temp_local, m.lmbd_dense_loss, m.lmbd_pixel_corr_weight,
                              m.lmbd_region_corr_weight, m.lmbd_not_corr_weight, m.momentum], dtype=np.float64)
+    rec["negative"] = np.array([m.negative_type.value, m.negative_scale], dtype=np.float64)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
     print(f"{name}: loss={float(loss):.6f} ins={float(loc['loss_instance']):.6f} "
           f"dense={float(loc['loss_dense']):.6f} ptr={int(m.queue_ptr)}")
@@ -246,11 +252,12 @@ class DenseEnc(nn.Module):
         self.neck = ref.DenseCLNeck(in_channels=2048, hid_channels=64, out_channels=128)
 
 
-def run_densecl_case(name, b, h, w, K, stride, seed, lmbd_coordinate=0.0):
+def run_densecl_case(name, b, h, w, K, stride, seed, lmbd_coordinate=0.0, symmetric=False, step=0, **kw):
     torch.manual_seed(seed)
     gen = torch.Generator().manual_seed(seed)
     m = blank_model(K, backbone_stride=stride, temp_local=0.2, lmbd_dense=0.5,
-                    pretrain_type=PretrainType.DENSECL, lmbd_coordinate=lmbd_coordinate)
+                    pretrain_type=PretrainType.PROPOSED_V2 if symmetric else PretrainType.DENSECL,
+                    lmbd_coordinate=lmbd_coordinate, use_symmetrical_loss=symmetric, **kw)
     m.encoder_q, m.encoder_k = DenseEnc(stride), DenseEnc(stride)
     for pq, pk in zip(m.encoder_q.parameters(), m.encoder_k.parameters()):
         pk.data.copy_(pq.data + 0.01 * torch.randn_like(pq))
@@ -265,15 +272,19 @@ def run_densecl_case(name, b, h, w, K, stride, seed, lmbd_coordinate=0.0):
                                                             "get_query_features", "get_key_features"):
             codes[const.co_name] = const
 
+    calls = {nm: [] for nm in codes}
+
     def prof(frame, event, arg):
         if event == "return":
             for nm, code in codes.items():
                 if frame.f_code is code:
-                    caps[nm] = dict(frame.f_locals)
-                    caps[nm]["__ret"] = arg
+                    d = dict(frame.f_locals)
+                    d["__ret"] = arg
+                    calls[nm].append(d)
     sys.setprofile(prof)
-    loss = m.forward_densecl(visualize=False, step=0, new_epoch=False, **inp)
+    loss = m.forward_densecl(visualize=False, step=step, new_epoch=False, **inp)
     sys.setprofile(None)
+    caps = {nm: c[0] for nm, c in calls.items()}
     loc, glob = caps["compute_local_loss"], caps["compute_global_loss"]
     rec["q_embed"], rec["k_embed"] = np_(loc["q_embed"]), np_(loc["k_embed"])
     rec["k_local"] = np_(loc["k_local"])
@@ -286,6 +297,15 @@ def run_densecl_case(name, b, h, w, K, stride, seed, lmbd_coordinate=0.0):
     rec["loss_global"] = np_(glob["__ret"])
     rec["k_local_pooled"] = np_(caps["get_key_features"]["k_local_proj_pooled"])
     rec["loss"] = np_(loss)
+    if symmetric:        # second pass (views swapped), reference builder.py:944-972
+        loc2, glob2 = calls["compute_local_loss"][1], calls["compute_global_loss"][1]
+        for k in ("q_embed", "k_embed", "k_local", "q_pixel_ids", "k_pixel_ids", "pos_global_k_idx", "pos_local"):
+            rec[k + "_2"] = np_(loc2[k])
+        rec["q_local_2"] = np_(calls["get_query_features"][1]["q_local"])
+        rec["loss_local_2"], rec["loss_global_2"] = np_(loc2["__ret"]), np_(glob2["__ret"])
+        rec["q_global_2"], rec["k_global_2"] = np_(glob2["q"]), np_(glob2["k"])
+        rec["k_local_pooled_2"] = np_(calls["get_key_features"][1]["k_local_proj_pooled"])
+        rec["step"] = np.int64(step)
     rec["queue_after"], rec["queue2_after"] = np_(m.queue), np_(m.queue2)
     rec["ptr_after"], rec["ptr2_after"] = np_(m.queue_ptr)[0], np_(m.queue2_ptr)[0]
     rec["cfg"] = np.array([b, h, w, K, stride], dtype=np.int64)
@@ -378,6 +398,15 @@ def main():
                  w_pixel=10.0, w_region=2.0, w_not=0.5, shared_regions=True)
     run_densecl_case("densecl_b2_128_k64", b=2, h=128, w=128, K=64, stride=32, seed=4)
     run_densecl_case("densecl_b2_96_k64_coord", b=2, h=96, w=96, K=64, stride=16, seed=5, lmbd_coordinate=0.3)
+    # experimental variants: NegativeType reshaping of the negative dense logits (builder.py:1332-1386) ...
+    for nt in ("NONE", "FIXED", "AVERAGE", "MEDIAN", "HARD"):
+        run_cp2_case(f"cp2_neg_{nt.lower()}", b=3, h=64, w=80, K=64, stride=16, seed=6, slim=True,
+                     pretrain_type=PretrainType.PROPOSED, mapping_type=ref.MappingType.PIXEL_REGION_ID,
+                     w_pixel=3.0, w_region=2.0, w_not=1.0, shared_regions=True, temp_local=0.5,
+                     negative_type=getattr(ref.NegativeType, nt), negative_scale=2)
+    # ... and the symmetric PROPOSED_V2 pass with coordinate mixing (builder.py:944-972)
+    run_densecl_case("densecl_v2_symmetric", b=2, h=96, w=96, K=64, stride=16, seed=8, lmbd_coordinate=0.3,
+                     symmetric=True, step=0)
     torch.distributed.destroy_process_group()
 
 

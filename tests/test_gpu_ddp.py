@@ -33,16 +33,22 @@ def _worker(rank, world, port, out_dir, mode="torch-sgd"):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.manual_seed(0)
-        cfg = Config.fromfile(os.path.join(ROOT, "configs", "config_pretrain_r18.py"))
-        model = builder.MODEL(cfg, rank=rank, K=256, pretrain_from_scratch=True, pretrain_type=PretrainType.CP2, device=dev,
-                              amp_dtype=torch.bfloat16, channels_last=True).to(dev).train()
+        densecl = mode.startswith("densecl")
+        cfg = Config.fromfile(os.path.join(ROOT, "configs", "config_moco.py" if densecl else "config_pretrain_r18.py"))
+        extra = dict(pretrain_type=PretrainType.CP2)
+        if densecl:      # BASELINE config 5; "-v2": the symmetric variant with the predictor heads in use
+            extra = dict(pretrain_type=PretrainType.DENSECL, lmbd_cp2_dense_loss=0.5, dense_logits_temp=0.2)
+            if mode == "densecl-v2":
+                extra.update(pretrain_type=PretrainType.PROPOSED_V2, use_symmetrical_loss=True, use_avgpool_global=True)
+        model = builder.MODEL(cfg, rank=rank, K=256, pretrain_from_scratch=True, device=dev,
+                              amp_dtype=torch.bfloat16, channels_last=True, **extra).to(dev).train()
         model.encoder_q.to(memory_format=torch.channels_last)
         model.encoder_k.to(memory_format=torch.channels_last)
         ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], output_device=0, broadcast_buffers=False,
                                                         gradient_as_bucket_view=True)
         steps = 3
-        if mode == "torch-sgd":
-            opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+        if mode in ("torch-sgd", "densecl", "densecl-v2"):
+            opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=0.01, momentum=0.9, weight_decay=1e-4)
         else:        # the bench / main.py configuration: FlatSGD, enough steps for the key-forward hipGraph to be replayed
             from cp2_amd.optim import FlatSGD
             opt = FlatSGD(ddp, 0.01, momentum=0.9, weight_decay=1e-4)
@@ -56,8 +62,8 @@ def _worker(rank, world, port, out_dir, mode="torch-sgd"):
             loss.backward()
             opt.step()
             assert torch.isfinite(loss)
-        assert model._side_stream is not None                                     # key branch ran on the side stream
-        if mode != "torch-sgd":
+        assert densecl or model._side_stream is not None                          # key branch ran on the side stream
+        if mode.startswith("flat"):
             assert model._key_graph is not None and any(e["graph"] is not None for e in model._key_graph.entries.values())
         torch.cuda.synchronize()
         g = model.encoder_q.backbone.conv1.weight.grad.detach().float().cpu()
@@ -70,7 +76,7 @@ def _worker(rank, world, port, out_dir, mode="torch-sgd"):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("mode", ["torch-sgd", "flat-gather", "flat-branch"])
+@pytest.mark.parametrize("mode", ["torch-sgd", "flat-gather", "flat-branch", "densecl", "densecl-v2"])
 def test_two_ranks_one_device_gloo(tmp_path, mode):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), mode), nprocs=world, join=True)

@@ -77,6 +77,28 @@ def test_loss_section_golden(golden_dir, name):
     assert_close(out.instance_neg_mean, g["instance_average_negative_scores"], 3e-6, what="instance - mean")
 
 
+@pytest.mark.parametrize("nt", ["none", "fixed", "average", "median", "hard"])
+def test_negative_type_golden(golden_dir, nt):
+    """NegativeType reshaping of the negative dense logits (reference builder.py:1332-1386) on the reference's recorded
+    encoder outputs: loss, dense loss, gradient and the logging statistics (which use the raw scores)."""
+    g = load(golden_dir, "cp2_neg_" + nt)
+    b = int(g["cfg"][0])
+    tg, tl, lmbd, wp, wr, wn, _ = [float(v) for v in g["cfg_f"]]
+    ids = tuple(G(g[k]).reshape(b, -1) for k in ("pixel_ids_a", "pixel_ids_b", "region_ids_a", "region_ids_b"))
+    q = G(g["q_feat"]).requires_grad_(True)
+    out = CF.cp2_loss_section(q, G(g["k_feat"]), G(g["mask_a"]), G(g["mask_b"]), G(g["queue_before"]), temp_global=tg,
+                              temp_local=tl, lmbd_dense=lmbd, ids=ids, weights=(wp, wr, wn), want_quartiles=True,
+                              negative_type=int(g["negative"][0]), negative_scale=float(g["negative"][1]))
+    out.loss.backward()
+    assert_close(out.loss_dense, g["loss_dense"], 2e-5, what="loss_dense")
+    assert_close(out.loss_instance, g["loss_instance"], 2e-5, what="loss_instance")
+    assert_close(out.loss, g["loss"], 2e-5, what="loss")
+    grad_close(q.grad, g["dq_feat"], "dq_feat")
+    assert_close(out.acc_dense, g["acc_dense"], 1e-4, what="acc_dense")
+    assert_close(out.dense_sample[:, 4], g["dense_negative_average"], 2e-6, what="dense -mean")
+    assert_close(out.dense_neg_quartiles, g["dense_negative_quartiles"], 3e-6, what="dense - quartiles")
+
+
 def test_feat_kernels_vs_oracle_and_channels_last():
     gen = torch.Generator().manual_seed(0)
     B, C, h, w = 5, 128, 9, 13
@@ -287,6 +309,29 @@ def test_densecl_local_positives_and_losses_golden(golden_dir, name):
     assert_close(loss_global, g["loss_global"], 2e-5, what="loss_global")
     assert_close((1 - lmbd) * loss_global + lmbd * loss_local, g["loss"], 2e-5, what="loss")
     assert torch.isfinite(ql.grad).all() and float(ql.grad.abs().max()) > 0
+
+
+def test_densecl_symmetric_golden(golden_dir):
+    """PROPOSED_V2 symmetric pass (reference builder.py:944-972): both passes' global and local losses on the recorded
+    tensors, summed as the reference does."""
+    from cp2_amd import builder
+    g = load(golden_dir, "densecl_v2_symmetric")
+    tg, tl, lmbd, lc = [float(v) for v in g["cfg_f"]]
+    b = g["q_local"].shape[0]
+    tot_l = tot_g = 0.0
+    for sfx in ("", "_2"):
+        pos, best = builder.densecl_local_positives(G(g["q_embed" + sfx]), G(g["k_embed" + sfx]), G(g["q_local" + sfx]),
+                                                    G(g["k_local" + sfx]), G(g["q_pixel_ids" + sfx]).reshape(b, -1),
+                                                    G(g["k_pixel_ids" + sfx]).reshape(b, -1), lc)
+        assert np.array_equal(best.cpu().numpy(), g["pos_global_k_idx" + sfx])
+        assert_close(pos.reshape(-1, 1), g["pos_local" + sfx], 3e-6, what="pos_local" + sfx)
+        loss_local = builder.queue_infonce(G(g["q_local" + sfx]), pos.reshape(-1), G(g["queue2_before"]), tl)
+        assert_close(loss_local, g["loss_local" + sfx], 2e-5, what="loss_local" + sfx)
+        qg = G(g["q_global" + sfx])
+        loss_global = builder.queue_infonce(qg, (qg * G(g["k_global" + sfx])).sum(1), G(g["queue_before"]), tg)
+        assert_close(loss_global, g["loss_global" + sfx], 2e-5, what="loss_global" + sfx)
+        tot_l, tot_g = tot_l + loss_local, tot_g + loss_global
+    assert_close((1 - lmbd) * tot_g + lmbd * tot_l, g["loss"], 4e-5, what="loss")
 
 
 @pytest.mark.parametrize("B,P", [(2, 196), (1, 132), (3, 1024), (5, 70)])

@@ -120,6 +120,28 @@ def test_densecl_forward_backward_runs_and_matches_oracle_losses():
     assert abs(0.5 * logs["train/loss_ins_step"] + 0.5 * logs["train/loss_dense_step"] - logs["train/loss_step"]) < 1e-5
 
 
+@pytest.mark.parametrize("flags", [dict(use_symmetrical_loss=True), dict(use_predictor=True),
+                                   dict(use_avgpool_global=True, use_symmetrical_loss=True, lmbd_coordinate=0.3)])
+def test_proposed_v2_variants_run_and_follow_the_reference_update_rule(flags):
+    """PROPOSED_V2 flags of reference builder.py:687-716, 944-972 end to end: finite loss, gradients for exactly the
+    parameters the chosen heads use, and at an even step the symmetric pass enqueues the SECOND pass's keys."""
+    model = small_model(K=512, pretrain_type=PretrainType.PROPOSED_V2, cfg_name="config_moco.py",
+                        lmbd_cp2_dense_loss=0.5, dense_logits_temp=0.2, **flags)
+    batch = synthetic.make_batch(4, 64, 64, DEV, seed=9)
+    keys = {}
+    enq = model._dequeue_and_enqueue
+    model._dequeue_and_enqueue = lambda k: (keys.__setitem__("global", k.clone()), enq(k))[1]
+    loss = model(visualize=False, step=0, new_epoch=False, **batch)
+    loss.backward()
+    assert torch.isfinite(loss) and int(model.queue_ptr) == 4 and int(model.queue2_ptr) == 4
+    assert torch.equal(model.queue[:, :4].t(), keys["global"])
+    pred = [p.grad is not None for p in model.encoder_q.neck.global_predictor.parameters()]
+    assert all(pred) == bool(flags.get("use_predictor", False)) and any(pred) == all(pred)
+    assert all(p.grad is None for p in model.encoder_q.decode_head.parameters())
+    logs = model.flush_logs()[0][1]
+    assert abs(0.5 * logs["train/loss_ins_step"] + 0.5 * logs["train/loss_dense_step"] - logs["train/loss_step"]) < 1e-5
+
+
 def test_flatten_preserves_channels_last_and_values():
     model = small_model()
     model.encoder_q.to(memory_format=torch.channels_last)

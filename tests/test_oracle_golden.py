@@ -115,6 +115,60 @@ def test_cp2_loss_section_golden(golden_dir, name):
     assert np.array_equal(qa.numpy(), g["queue_after"]) and ptr == int(g["ptr_after"])
 
 
+@pytest.mark.parametrize("nt", ["none", "fixed", "average", "median", "hard"])
+def test_negative_type_golden(golden_dir, nt):
+    """the NegativeType reshaping of the negative dense logits (reference builder.py:1332-1386), recorded
+    from the reference for the same inputs under every type; HARD must equal NONE (it edits a copy)."""
+    g = load(golden_dir, "cp2_neg_" + nt)
+    b, h, w, K, stride, inc_bg = [int(v) for v in g["cfg"]]
+    tg, tl, lmbd, wp, wr, wn, m = [float(v) for v in g["cfg_f"]]
+    ntype, nscale = int(g["negative"][0]), float(g["negative"][1])
+    assert ntype == {"none": O.NEG_NONE, "fixed": O.NEG_FIXED, "average": O.NEG_AVERAGE, "median": O.NEG_MEDIAN, "hard": O.NEG_HARD}[nt]
+    q = T(g["q_feat"]).clone().requires_grad_(True)
+    mi = (T(g["mask_a"]), T(g["mask_b"]), T(g["pixel_ids_a"]), T(g["pixel_ids_b"]), T(g["region_ids_a"]), T(g["region_ids_b"]))
+    r = O.cp2_loss_section(q, T(g["k_feat"]), None, None, None, None, None, None, T(g["queue_before"]), output_stride=stride,
+                           temp_global=tg, temp_local=tl, lmbd_dense=lmbd, include_background=bool(inc_bg), w_pixel=wp,
+                           w_region=wr, w_not=wn, with_stats=True, negative_type=ntype, negative_scale=nscale, masks_and_ids=mi)
+    r["loss"].backward()
+    assert np.array_equal(r["corr_weights"].numpy().astype(np.float32), g["corr_weights"].astype(np.float32))
+    close(r["logits_dense_reshaped"].detach(), g["_logits_dense"])      # the reference edits _logits_dense in place
+    close(r["logits_dense_scaled"].detach(), g["logits_dense"], 2e-6)
+    for k in ("loss_instance", "loss_dense", "loss"):
+        close(r[k].detach(), g[k], 2e-6)
+    close(q.grad, g["dq_feat"], 1e-6)
+    close(r["dense_stats"]["negative"]["average"], g["dense_negative_average"])
+    close(r["dense_stats"]["negative"]["quartiles"], g["dense_negative_quartiles"])
+    close(r["acc_dense"], g["acc_dense"])
+    if nt == "hard":
+        none = load(golden_dir, "cp2_neg_none")
+        for k in ("loss", "loss_dense", "dq_feat", "logits_dense"):
+            assert np.array_equal(g[k], none[k]), k
+
+
+def test_densecl_symmetric_golden(golden_dir):
+    """PROPOSED_V2 with use_symmetrical_loss (reference builder.py:944-972): both passes' losses are summed, and at an
+    even step the SECOND pass's keys go into the queues."""
+    g = load(golden_dir, "densecl_v2_symmetric")
+    tg, tl, lmbd, lc = [float(v) for v in g["cfg_f"]]
+    tot_l = tot_g = 0.0
+    for sfx in ("", "_2"):
+        loss_l, pos, _, best = O.densecl_local_loss(T(g["q_embed" + sfx]), T(g["k_embed" + sfx]), T(g["q_local" + sfx]),
+                                                    T(g["k_local" + sfx]), T(g["q_pixel_ids" + sfx]), T(g["k_pixel_ids" + sfx]),
+                                                    T(g["queue2_before"]), temp_local=tl, lmbd_coordinate=lc)
+        assert np.array_equal(best.numpy(), g["pos_global_k_idx" + sfx])
+        close(pos.reshape(-1, 1), g["pos_local" + sfx])
+        close(loss_l, g["loss_local" + sfx], 2e-6)
+        loss_g = O.densecl_global_loss(T(g["q_global" + sfx]), T(g["k_global" + sfx]), T(g["queue_before"]), tg)
+        close(loss_g, g["loss_global" + sfx], 2e-6)
+        tot_l, tot_g = tot_l + loss_l, tot_g + loss_g
+    close((1 - lmbd) * tot_g + lmbd * tot_l, g["loss"], 2e-6)
+    assert int(g["step"]) % 2 == 0
+    qa, ptr = O.dequeue_and_enqueue(T(g["queue_before"]), 0, T(g["k_global_2"]))
+    assert np.array_equal(qa.numpy(), g["queue_after"]) and ptr == int(g["ptr_after"])
+    qa2, ptr2 = O.dequeue_and_enqueue(T(g["queue2_before"]), 0, T(g["k_local_pooled_2"]))
+    assert np.array_equal(qa2.numpy(), g["queue2_after"]) and ptr2 == int(g["ptr2_after"])
+
+
 def test_ema_inside_forward_golden(golden_dir):
     g = load(golden_dir, "cp2_b4_64_k64")
     m = float(g["cfg_f"][6])
