@@ -29,6 +29,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 BF16_DENSE_PEAK_TFLOPS = 2500.0
+F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32: the f32 vector rate (same guide, "Matrix cores")
 
 
 def parse():
@@ -58,8 +59,9 @@ def parse():
                         "on = the key encoder too, off = serial (auto at N = 1)")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     p.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
-    p.add_argument("--cpu-batch", type=int, default=8)
-    p.add_argument("--cpu-steps", type=int, default=2)
+    p.add_argument("--cpu-batch", type=int, default=32, help="CPU baseline: images per step (BASELINE.md section 3: the same b)")
+    p.add_argument("--cpu-steps", type=int, default=5, help="CPU baseline: timed steps (after --cpu-warmup)")
+    p.add_argument("--cpu-warmup", type=int, default=2)
     return p.parse_args()
 
 
@@ -163,6 +165,8 @@ def main():
     for i in range(args.warmup + (4 if use_graph else 0)):
         one_step(i, False)
     torch.cuda.synchronize()
+    if not use_graph:
+        ops.PROFILE = {}           # every profiled launch of the timed steps carries its own start/stop hipEvents
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -182,6 +186,7 @@ def main():
     loss_val = float(loss)
     assert loss_val == loss_val, "loss is NaN"
 
+    prof, ops.PROFILE = ops.PROFILE or {}, None
     ema_ms = sum(ev.elapsed_ms() for ev in ema_events) / len(ema_events)
     n_param_floats = model._flat_q.numel()
     # read k, read q, write k (12 B) + the bf16 copy of the new key weights for the key encoder (2 B) per parameter slot
@@ -196,6 +201,30 @@ def main():
                 traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    # per-kernel figures of the other hand-written kernels of the step, each from its own launches' events
+    C, K, P = 128, args.queue, (hw // model.output_stride) ** 2
+
+    def avg_ms(name):
+        evs = prof.get(name) or []
+        return sum(e.elapsed_ms() for e in evs) / len(evs) if evs else None
+    kernels = []
+
+    def add(name, kernel, bound, work, unit, peak, note):
+        ms = avg_ms(name)
+        if ms:
+            ach = work / (ms * 1e-3) / (1e9 if unit == "GB/s" else 1e12)
+            kernels.append({"kernel": kernel, "bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": unit,
+                            "frac": round(ach / peak, 4), "avg_launch_us": round(ms * 1e3, 2), "work_per_launch": work, "note": note})
+    add("rowkey_fwd", "rowkey_small_kernel (instance InfoNCE: q_pos x queue, builder.py:1395-1428)", "hbm", 4 * C * K, "GB/s",
+        HBM_PEAK_GBS, "algorithmic bytes = the fp32 queue read once (4*C*K); with quartile logging on the launch also writes the b x K logits")
+    add("dense_fwd", "dense_fwd_kernel (P x P logits + column soft-max statistics, builder.py:1289-1292,1431-1437)", "mfma", 2.0 * b * P * P * C,
+        "TFLOP/s", F32_MFMA_PEAK_TFLOPS, "f32-input MFMA; at P=196 the launch is latency-bound (64 (sample, tile) items)")
+    add("dense_bwd", "dense_bwd_kernel (recomputed logits + gradient product)", "mfma", 4.0 * b * P * P * C, "TFLOP/s", F32_MFMA_PEAK_TFLOPS,
+        "f32-input MFMA, two products per pair")
+    add("sgd_flat", "sgd_flat_kernel (SGD momentum + weight decay + bf16 weight image, main.py:467-477)", "hbm", 22 * n_param_floats, "GB/s",
+        HBM_PEAK_GBS, "22 B per parameter slot")
+    add("quantiles", "quantiles_kernel (3 x 3 logging quartiles of the step in one launch)", "hbm", 4 * (b * K + 2 * b * P * P), "GB/s",
+        HBM_PEAK_GBS, "one workgroup per row, three passes: latency / VALU bound, not a streaming kernel")
     imgs = b * world * args.steps
     value = imgs / dt
     out = {
@@ -212,7 +241,9 @@ def main():
         "roofline": {"kernel": "ema_flat_kernel (momentum update of the key encoder, builder.py:557-567)", "bound": "hbm",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "traffic_source": "profiles/ema_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" if traffic else None,
                      "bytes_per_launch": ema_bytes, "avg_launch_ms": round(ema_ms, 4)},
+        "roofline_kernels": kernels,
         "step_compute": {"flops_per_img": round(flops_img / 1e9, 2), "unit": "GFLOP (encoders fwd+bwd, flop counter)",
                          "achieved_tflops_per_gpu": round(flops_img * b / (dt / args.steps) / 1e12, 1),
                          "frac_of_bf16_dense_peak": round(flops_img * b / (dt / args.steps) / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4)},
@@ -220,10 +251,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.cpu_step import time_cpu_baseline
         ips, threads, secs = time_cpu_baseline(cfg, synthetic.make_batch, args.cpu_batch, hw, hw, args.queue,
-                                               steps=args.cpu_steps, warmup=1)
+                                               steps=args.cpu_steps, warmup=args.cpu_warmup)
         out["cpu_baseline"] = {"value": round(ips, 3), "unit": "images/sec", "cores": threads, "kind": "port",
                                "sample": f"{args.cpu_steps} steps of {args.cpu_batch} images ({hw}x{hw}, queue {args.queue}, "
-                                         f"same model) after 1 warm-up step, fp32, {secs:.1f} s",
+                                         f"same model) after {args.cpu_warmup} warm-up steps, fp32, {secs:.1f} s",
                                "split_ms_per_step": time_cpu_baseline.last_split_ms}
     if rank == 0:
         print(json.dumps(out), flush=True)

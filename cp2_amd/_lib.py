@@ -16,6 +16,7 @@ _P = c_void_p  # every device pointer crosses the ABI as a plain address
 SIGNATURES = {
     "cp2_version": [],
     "cp2_error_string": [c_int],
+    "cp2_profile_next_launch": [_P, _P],
     "cp2_compose_mask": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "cp2_strided_gather_f32": [_P, _P, c_int, c_int, c_int, c_int, _P],
     "cp2_strided_gather_i64": [_P, _P, c_int, c_int, c_int, c_int, _P],

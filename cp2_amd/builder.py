@@ -389,12 +389,40 @@ class MODEL(nn.Module):
 
     # ------------------------------------------------------------------ queue
     @torch.no_grad()
-    def _dequeue_and_enqueue(self, keys):
-        ops.enqueue(self.queue, concat_all_gather(keys.contiguous()), self.queue_ptr)
+    def _enqueue(self, queue, ptr, keys):
+        """All-gather the keys over the ranks (C4) and write them into the queue (reference builder.py:569-607).  With
+        more than one rank both run on the side HIP stream: nothing on the main stream needs the updated queue before
+        the NEXT step's loss section, which waits for `_enqueue_done` (so does anything that reads the queue from
+        outside: wait_enqueue())."""
+        keys = keys.contiguous()
+        cur = torch.cuda.current_stream()
+        if not cdist.multi() or torch.cuda.is_current_stream_capturing():
+            ops.enqueue(queue, keys, ptr)
+            return
+        side = self._key_stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            keys.record_stream(side)
+            ops.enqueue(queue, concat_all_gather(keys), ptr)
+            self._enqueue_done = torch.cuda.Event()
+            self._enqueue_done.record(side)
 
-    @torch.no_grad()
+    def state_dict(self, *args, **kwargs):
+        self.wait_enqueue()
+        return super().state_dict(*args, **kwargs)
+
+    def wait_enqueue(self):
+        """Make the current stream wait for an enqueue still running on the side stream."""
+        ev = getattr(self, "_enqueue_done", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self._enqueue_done = None
+
+    def _dequeue_and_enqueue(self, keys):
+        self._enqueue(self.queue, self.queue_ptr, keys)
+
     def _dequeue_and_enqueue2(self, keys):
-        ops.enqueue(self.queue2, concat_all_gather(keys.contiguous()), self.queue2_ptr)
+        self._enqueue(self.queue2, self.queue2_ptr, keys)
 
     # ------------------------------------------------------------------ shuffle-BN
     @torch.no_grad()
@@ -415,6 +443,7 @@ class MODEL(nn.Module):
 
     # ------------------------------------------------------------------ dispatch
     def forward(self, **kwargs):
+        self.wait_enqueue()                     # the previous step's queue update (side stream when world size > 1)
         if self._flat_q_bf16 is not None:       # bf16 weight image in use: rebuild it if a parameter changed elsewhere
             self.flatten_parameters()
             self._refresh_query_shadow()
@@ -463,7 +492,7 @@ class MODEL(nn.Module):
         cur = torch.cuda.current_stream()
         mode = self.overlap_key_branch
         if mode is None:
-            mode = "gather" if cdist.world_size() > 1 else False
+            mode = "gather" if cdist.multi() else False
         side = self._key_stream() if mode else cur
         if side is not cur:
             side.wait_stream(cur)
@@ -601,6 +630,7 @@ class MODEL(nn.Module):
         return r
 
     def on_train_epoch_end(self, step):
+        self.wait_enqueue()
         self.flush_logs()
         if self.rank == 0 and self.log_fn is not None:
             rec = {"train/loss": self.loss_o.avg, "train/loss_ins": self.loss_i.avg, "train/loss_dense": self.loss_d.avg}

@@ -1,6 +1,7 @@
 // Shared helpers for the libcp2hip.so kernels (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include "../../include/cp2hip.h"
 
@@ -16,6 +17,23 @@ static inline int cp2_launch_status() {
 
 static inline bool cp2_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int cp2_cdiv(int64_t a, int64_t b) { return static_cast<int>((a + b - 1) / b); }
+
+// Measurement aid (bench.py's per-kernel roofline figures): cp2_profile_next_launch(start, stop) arms a pair of
+// caller-owned hipEvent_t for the calling thread; the next launch made through CP2_LAUNCH_PROFILED attaches them to
+// the kernel itself (hipExtLaunchKernelGGL), so hipEventElapsedTime is that kernel's own duration, as
+// rocprofv3 --kernel-trace reports it.  Nothing is armed in normal operation and the plain launch runs.
+struct Cp2LaunchEvents { hipEvent_t start = nullptr; hipEvent_t stop = nullptr; };
+inline thread_local Cp2LaunchEvents cp2_next_events;
+#define CP2_LAUNCH_PROFILED(kernel, grid, block, lds, stream, ...)                                                    \
+    do {                                                                                                             \
+        if (cp2_next_events.start) {                                                                                 \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, cp2_next_events.start, cp2_next_events.stop, 0,   \
+                                  __VA_ARGS__);                                                                      \
+            cp2_next_events = Cp2LaunchEvents{};                                                                     \
+        } else {                                                                                                     \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                       \
+        }                                                                                                            \
+    } while (0)
 
 constexpr int kWave = 64;  // gfx950 wavefront width
 

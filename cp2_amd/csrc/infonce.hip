@@ -728,7 +728,7 @@ CP2_API int cp2_rowkey_infonce_fwd(const float* rows, int RP, int64_t r_sn, int6
                        : (wu ? rowkey_fwd_bf16x3_kernel<true, false> : rowkey_fwd_bf16x3_kernel<false, false>);
         hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, BF_LDS);
         if (e_ != hipSuccess) return (int)e_;
-        hipLaunchKernelGGL(kfn, grid, block, BF_LDS, cp2_stream(stream), a, pre ? ks : nullptr);
+        CP2_LAUNCH_PROFILED(kfn, grid, block, BF_LDS, cp2_stream(stream), a, pre ? ks : nullptr);
         return cp2_launch_status();
     }
 #define CP2_LAUNCH_RK(wr_, wk_, wu_)                                                                            \
@@ -737,7 +737,7 @@ CP2_API int cp2_rowkey_infonce_fwd(const float* rows, int RP, int64_t r_sn, int6
         hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                                 \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
         if (e_ != hipSuccess) return (int)e_;                                                                   \
-        hipLaunchKernelGGL(kfn, grid, block, lds, cp2_stream(stream), a);                                       \
+        CP2_LAUNCH_PROFILED(kfn, grid, block, lds, cp2_stream(stream), a);                                      \
     } while (0)
     if (WR == 1) { if (wu) CP2_LAUNCH_RK(1, 4, true); else CP2_LAUNCH_RK(1, 4, false); }
     else if (WR == 2) { if (wu) CP2_LAUNCH_RK(2, 2, true); else CP2_LAUNCH_RK(2, 2, false); }
@@ -1154,10 +1154,10 @@ CP2_API int cp2_dense_infonce_fwd(const float* q_dense, const float* k_dense, co
     const dim3 grid(cp2_cdiv(P, 32 * DNW) * B * S);
     const size_t lds = sizeof(DenseLds);
     if (negative_mode) {
-        if (pix_a) hipLaunchKernelGGL((dense_fwd_kernel<true, true>), grid, dim3(DNT), lds, cp2_stream(stream), a);
-        else hipLaunchKernelGGL((dense_fwd_kernel<false, true>), grid, dim3(DNT), lds, cp2_stream(stream), a);
-    } else if (pix_a) hipLaunchKernelGGL((dense_fwd_kernel<true, false>), grid, dim3(DNT), lds, cp2_stream(stream), a);
-    else hipLaunchKernelGGL((dense_fwd_kernel<false, false>), grid, dim3(DNT), lds, cp2_stream(stream), a);
+        if (pix_a) CP2_LAUNCH_PROFILED((dense_fwd_kernel<true, true>), grid, dim3(DNT), lds, cp2_stream(stream), a);
+        else CP2_LAUNCH_PROFILED((dense_fwd_kernel<false, true>), grid, dim3(DNT), lds, cp2_stream(stream), a);
+    } else if (pix_a) CP2_LAUNCH_PROFILED((dense_fwd_kernel<true, false>), grid, dim3(DNT), lds, cp2_stream(stream), a);
+    else CP2_LAUNCH_PROFILED((dense_fwd_kernel<false, false>), grid, dim3(DNT), lds, cp2_stream(stream), a);
     rc = cp2_launch_status();
     if (rc) return rc;
     if (S > 1) {
@@ -1190,10 +1190,10 @@ CP2_API int cp2_dense_infonce_bwd(const float* q_dense, const float* k_dense, co
     const dim3 grid(cp2_cdiv(P, 32 * DNW) * B * S);
     const size_t lds = sizeof(DenseLds);
     if (negative_mode) {
-        if (pix_a) hipLaunchKernelGGL((dense_bwd_kernel<true, true>), grid, dim3(DNT), lds, cp2_stream(stream), a);
-        else hipLaunchKernelGGL((dense_bwd_kernel<false, true>), grid, dim3(DNT), lds, cp2_stream(stream), a);
-    } else if (pix_a) hipLaunchKernelGGL((dense_bwd_kernel<true, false>), grid, dim3(DNT), lds, cp2_stream(stream), a);
-    else hipLaunchKernelGGL((dense_bwd_kernel<false, false>), grid, dim3(DNT), lds, cp2_stream(stream), a);
+        if (pix_a) CP2_LAUNCH_PROFILED((dense_bwd_kernel<true, true>), grid, dim3(DNT), lds, cp2_stream(stream), a);
+        else CP2_LAUNCH_PROFILED((dense_bwd_kernel<false, true>), grid, dim3(DNT), lds, cp2_stream(stream), a);
+    } else if (pix_a) CP2_LAUNCH_PROFILED((dense_bwd_kernel<true, false>), grid, dim3(DNT), lds, cp2_stream(stream), a);
+    else CP2_LAUNCH_PROFILED((dense_bwd_kernel<false, false>), grid, dim3(DNT), lds, cp2_stream(stream), a);
     rc = cp2_launch_status();
     if (rc || S == 1) return rc;
     const int64_t n = (int64_t)B * CH * P;

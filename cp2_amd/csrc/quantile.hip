@@ -239,7 +239,7 @@ static int quant_launch(const QuantJobs& jobs, int njobs, hipStream_t stream) {
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e_ != hipSuccess) return (int)e_;
     }
-    hipLaunchKernelGGL(quantiles_kernel, dim3(jobs.first_row[njobs]), dim3(QT), lds, stream, jobs);
+    CP2_LAUNCH_PROFILED(quantiles_kernel, dim3(jobs.first_row[njobs]), dim3(QT), lds, stream, jobs);
     return cp2_launch_status();
 }
 

@@ -421,7 +421,7 @@ int rowkey_small_launch(const RowKeyArgs& a, int nsplit, bool with_u, hipStream_
         const char* e = getenv("CP2_ROWKEY_STAGGER");
         stagger = e ? atoi(e) : 0;   // measured: no gain from staggering (f32 MFMA and VALU share one pipe)
     }
-    hipLaunchKernelGGL(kfn, dim3(nsplit), dim3(64 * SM_WAVES), SM_LDS, stream, a, tpw, stagger);
+    CP2_LAUNCH_PROFILED(kfn, dim3(nsplit), dim3(64 * SM_WAVES), SM_LDS, stream, a, tpw, stagger);
     return cp2_launch_status();
 }
 

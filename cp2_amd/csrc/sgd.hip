@@ -122,7 +122,7 @@ CP2_API int cp2_sgd_flat(float* p, float* momentum_buf, void* p_bf16, const void
         const int nblk = tensor_first_block[t1] - tensor_first_block[t0];
         if (nblk < 0) return CP2_ERR_SHAPE;
         if (!any || nblk == 0) continue;
-        hipLaunchKernelGGL(sgd_flat_kernel, dim3((unsigned)nblk), dim3(kSgdThreads), 0, s, a);
+        CP2_LAUNCH_PROFILED(sgd_flat_kernel, dim3((unsigned)nblk), dim3(kSgdThreads), 0, s, a);
     }
     return cp2_launch_status();
 }

@@ -16,6 +16,16 @@ def world_size() -> int:
     return dist.get_world_size() if is_dist() else 1
 
 
+# Rehearsal switch (tests/test_gpu_nccl.py): run every collective and side-stream branch even with a single rank, so
+# the RCCL calls of the multi-GPU run are exercised on a one-GPU box.  Never set in production.
+FORCE_COLLECTIVES = False
+
+
+def multi() -> bool:
+    """True when the collectives of the hot path have to run (more than one rank, or the rehearsal switch)."""
+    return is_dist() and (world_size() > 1 or FORCE_COLLECTIVES)
+
+
 def rank() -> int:
     return dist.get_rank() if is_dist() else 0
 
@@ -25,7 +35,7 @@ def concat_all_gather(tensor: torch.Tensor) -> torch.Tensor:
     """All ranks' tensors concatenated on dim 0, in rank order; no gradient
     (reference builder.py:1710-1722).  One all_gather_into_tensor into a single
     pre-sized buffer instead of W temporaries plus a cat."""
-    if world_size() == 1:
+    if not multi():
         return tensor
     tensor = tensor.contiguous()
     out = torch.empty((world_size() * tensor.shape[0],) + tuple(tensor.shape[1:]), dtype=tensor.dtype,
@@ -42,7 +52,7 @@ def make_shuffle_index(batch_all: int, device, generator: Optional[torch.Generat
     """Shuffle-BN permutation: drawn on the host from the global torch RNG (or `generator`)
     and overwritten with rank 0's by a broadcast, exactly as reference builder.py:618-621."""
     idx = torch.randperm(batch_all, generator=generator).to(device)
-    if world_size() > 1:
+    if multi():
         dist.broadcast(idx, src=0)
     return idx
 

@@ -41,6 +41,20 @@ def _opt(t: Optional[torch.Tensor], name: str, dtype=None) -> Optional[int]:
     return None if t is None else _dev(t, name, dtype)
 
 
+# bench.py sets PROFILE to a dict {kernel family: [hipevents.EventPair, ...]}: each profiled launch then carries its
+# own start / stop events (cp2_profile_next_launch), i.e. kernel-exact durations measured inside the run.
+PROFILE = None
+
+
+def _profile(name: str) -> None:
+    if PROFILE is None or torch.cuda.is_current_stream_capturing():
+        return
+    from .hipevents import EventPair
+    ev = EventPair()
+    _lib.check(_lib.load().cp2_profile_next_launch(ev.start, ev.stop), "cp2_profile_next_launch")
+    PROFILE.setdefault(name, []).append(ev)
+
+
 def ds_size(n: int, stride: int) -> int:
     """len(range(stride // 2, n, stride))"""
     return (n - stride // 2 + stride - 1) // stride
@@ -192,6 +206,7 @@ def sgd_flat(plan: SgdFlatPlan, p: torch.Tensor, buf: torch.Tensor, p_bf16: Opti
     lr_dev = None
     if isinstance(lr, torch.Tensor):
         lr_dev, lr = _dev(lr, "lr", torch.float32), 0.0
+    _profile("sgd_flat")
     rc = lib.cp2_sgd_flat(_dev(p, "p", torch.float32), _dev(buf, "momentum_buf", torch.float32),
                           _opt(p_bf16, "p_bf16", torch.bfloat16), plan.grads, plan.ntensors, plan.blk_tab.data_ptr(),
                           plan.first, float(np.float32(lr)), lr_dev, float(np.float32(momentum)),
@@ -373,6 +388,7 @@ def rowkey_infonce(rows: torch.Tensor, row_layout: Tuple[int, int, int, int], R:
     ksplit = torch.empty(4 * C * K, dtype=torch.bfloat16, device=dev) if (prec == 1 and R > 64 and K % 8 == 0 and presplit) else None
     if not rows.is_cuda or rows.dtype != torch.float32:
         raise _lib.Cp2LibraryError("rowkey_infonce: rows must be a float32 GPU tensor")
+    _profile("rowkey_fwd" if R <= 32 else "rowkey_fwd_rows")
     rc = lib.cp2_rowkey_infonce_fwd(rows.data_ptr(), RP, sn, sx, sc, R, _dev(keys, "keys", torch.float32), K,
                                     _dev(extras, "extras", torch.float32), NE, float(temperature), ns,
                                     part_m.data_ptr(), part_s.data_ptr(), part_cnt.data_ptr(), _opt(part_U, "part_U"),
@@ -433,6 +449,7 @@ def dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temperature: float, ids=
     pa, pb, ra, rb = _ids4(ids)
     S = lib.cp2_dense_num_splits(B, P) if split else 1
     split_ws = torch.empty(7 * S * B * P, dtype=torch.float32, device=dev) if S > 1 else None
+    _profile("dense_fwd")
     rc = lib.cp2_dense_infonce_fwd(_dev(q_dense, "q_dense", torch.float32), _dev(k_dense, "k_dense", torch.float32),
                                    _dev(mask_a, "mask_a", torch.float32), _dev(mask_b, "mask_b", torch.float32),
                                    pa, pb, ra, rb, float(weights[0]), float(weights[1]), float(weights[2]),
@@ -454,6 +471,7 @@ def dense_infonce_bwd(q_dense, k_dense, mask_a, mask_b, temperature: float, fwd:
     pa, pb, ra, rb = _ids4(ids)
     S = lib.cp2_dense_num_splits(B, P) if split else 1
     split_ws = torch.empty(S * B * C * P, dtype=torch.float32, device=q_dense.device) if S > 1 else None
+    _profile("dense_bwd")
     rc = lib.cp2_dense_infonce_bwd(_dev(q_dense, "q_dense"), _dev(k_dense, "k_dense"), _dev(mask_a, "mask_a"),
                                    _dev(mask_b, "mask_b"), pa, pb, ra, rb, float(weights[0]), float(weights[1]),
                                    float(weights[2]), float(temperature), fwd.lse.data_ptr(), fwd.sample_scal.data_ptr(),
@@ -510,6 +528,7 @@ def masked_quantiles_multi(jobs, q: Optional[torch.Tensor] = None):
             raise _lib.Cp2LibraryError("masked_quantiles_multi: x must be a float32 GPU tensor")
     ma = [_opt(j.get("mask_a"), "mask_a", torch.float32) for j in jobs]
     mb = [_opt(j.get("mask_b"), "mask_b", torch.float32) for j in jobs]
+    _profile("quantiles")
     rc = lib.cp2_masked_quantiles_multi(
         n, P_(*[j["x"].data_ptr() for j in jobs]), I64(*[j["stride_row"] for j in jobs]), I64(*[j["stride_elem"] for j in jobs]),
         I32(*[j["R"] for j in jobs]), I32(*[j["N"] for j in jobs]), P_(*ma), P_(*mb),

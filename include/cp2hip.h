@@ -40,6 +40,11 @@ int cp2_version(void);
 /* Human-readable text for a return code of this library. */
 const char* cp2_error_string(int code);
 
+/* Measurement aid: the next launch of the dominant kernel of cp2_rowkey_infonce_fwd, cp2_dense_infonce_fwd / _bwd,
+ * cp2_masked_quantiles(_multi) or cp2_sgd_flat made by the calling thread carries these caller-owned hipEvent_t
+ * (start, stop), so hipEventElapsedTime gives that kernel's own duration.  One shot; NULL, NULL disarms. */
+int cp2_profile_next_launch(void* start_event, void* stop_event);
+
 /* ---- a1 (+ mask part of a2): copy-paste composition ---- builder.py:1146-1159
  * mask = (bg[:,0] == 0) ? 1 : 0;  out_img = img * mask + bg   (bit-exact, no FMA)
  * img, bg, out_img: [B,3,H,W]; mask_full: [B,H,W] or NULL;
