@@ -39,6 +39,8 @@ SIGNATURES = {
     "cp2_dense_num_splits": [c_int, c_int],
     "cp2_dense_infonce_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, _P, _P, _P, _P,
                               _P, _P, _P, _P, _P, _P, c_int, c_float, _P, c_int, c_int, c_int, _P],
+    "cp2_crop_resize_flip": [_P, c_int, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
+    "cp2_erase_rect": [_P, _P, c_int, c_int, c_int, _P],
     "cp2_sgd_flat": [_P, _P, _P, _P, c_int, _P, _P, c_float, _P, c_float, c_float, _P],
     "cp2_bf16_image": [_P, _P, c_int64, _P],
     "cp2_wgrad1x1_num_splits": [c_int, c_int, c_int],

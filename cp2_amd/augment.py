@@ -1,0 +1,134 @@
+"""On-device input pipeline: the two-crop foreground views with their pixel / region id maps and the
+two erased background views of a CP2 step, made by HIP kernels (csrc/augment.hip) from a dataset that is resident in
+HBM, with the random parameters drawn on the host the way the reference's transforms draw them:
+
+    reference                                               here
+    loader.py:50-118  A.RandomResizedCrop + A.HorizontalFlip  rrc_params() + flips -> ops.crop_resize_flip (image + ids)
+    loader.py:39-43,66-73  pixel ids at pixel_ids_stride       id_stride argument of the kernel
+    main.py:204-225   RandomResizedCrop, flip, RandomErasing   rrc_params(), erase_params() -> crop_resize_flip + erase_rect
+    main.py:263-289   three DistributedSamplers (seeds 0/1024/2048)   EpochSampler
+
+The photometric transforms of the reference (ColorJitter, ToGray, GaussianBlur: image values only, no effect on the
+input contract or on the id maps) are not part of this module.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+def rrc_params(rng: np.random.Generator, n: int, hs: int, ws: int, scale=(0.2, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0)) -> np.ndarray:
+    """RandomResizedCrop.get_params for n samples (the algorithm torchvision and albumentations share): up to ten
+    draws of (area fraction ~ U(scale), log aspect ~ U(log ratio)); the first box that fits is placed uniformly; if none
+    fits, the central crop with the aspect clamped into `ratio`.  Returns int32 [n, 4] = top, left, h, w."""
+    area = float(hs * ws)
+    ta = area * rng.uniform(scale[0], scale[1], size=(n, 10))
+    ar = np.exp(rng.uniform(math.log(ratio[0]), math.log(ratio[1]), size=(n, 10)))
+    w = np.rint(np.sqrt(ta * ar)).astype(np.int64)
+    h = np.rint(np.sqrt(ta / ar)).astype(np.int64)
+    ok = (w > 0) & (w <= ws) & (h > 0) & (h <= hs)
+    first = np.where(ok.any(1), ok.argmax(1), -1)
+    in_ratio = ws / hs
+    if in_ratio < min(ratio):
+        fw, fh = ws, int(round(ws / min(ratio)))
+    elif in_ratio > max(ratio):
+        fh, fw = hs, int(round(hs * max(ratio)))
+    else:
+        fw, fh = ws, hs
+    rows = np.arange(n)
+    hh = np.where(first >= 0, h[rows, np.maximum(first, 0)], fh)
+    ww = np.where(first >= 0, w[rows, np.maximum(first, 0)], fw)
+    top = np.where(first >= 0, np.floor(rng.random(n) * (hs - hh + 1)).astype(np.int64), (hs - hh) // 2)
+    left = np.where(first >= 0, np.floor(rng.random(n) * (ws - ww + 1)).astype(np.int64), (ws - ww) // 2)
+    return np.stack([top, left, hh, ww], 1).astype(np.int32)
+
+
+def erase_params(rng: np.random.Generator, n: int, h: int, w: int, scale=(0.5, 0.8), ratio=(0.8, 1.25)) -> np.ndarray:
+    """RandomErasing.get_params (torchvision): ten draws of (area fraction, log aspect); the first box strictly smaller
+    than the image in both directions is placed uniformly; none -> nothing is erased (h = w = 0).  int32 [n, 4]."""
+    area = float(h * w)
+    ea = area * rng.uniform(scale[0], scale[1], size=(n, 10))
+    ar = np.exp(rng.uniform(math.log(ratio[0]), math.log(ratio[1]), size=(n, 10)))
+    eh = np.rint(np.sqrt(ea * ar)).astype(np.int64)
+    ew = np.rint(np.sqrt(ea / ar)).astype(np.int64)
+    ok = (eh < h) & (ew < w)
+    first = np.where(ok.any(1), ok.argmax(1), -1)
+    rows = np.arange(n)
+    hh = np.where(first >= 0, eh[rows, np.maximum(first, 0)], 0)
+    ww = np.where(first >= 0, ew[rows, np.maximum(first, 0)], 0)
+    top = np.floor(rng.random(n) * (h - hh + 1)).astype(np.int64)
+    left = np.floor(rng.random(n) * (w - ww + 1)).astype(np.int64)
+    return np.stack([top, left, hh, ww], 1).astype(np.int32)
+
+
+def crop_table(src_index: np.ndarray, boxes: np.ndarray, flips: np.ndarray) -> np.ndarray:
+    """int32 [n, 8] parameter rows of cp2_crop_resize_flip."""
+    t = np.zeros((len(src_index), 8), dtype=np.int32)
+    t[:, 0], t[:, 1:5], t[:, 5] = src_index, boxes, flips
+    return t
+
+
+class EpochSampler:
+    """DistributedSampler(shuffle=True, drop_last=True, seed) of reference main.py:263-272: one permutation of the
+    dataset per epoch from torch.Generator(seed + epoch), truncated to a multiple of the world size, strided by rank."""
+
+    def __init__(self, n: int, world: int, rank: int, seed: int):
+        self.n, self.world, self.rank, self.seed = n, world, rank, seed
+        self.per_rank = n // world
+
+    def indices(self, epoch: int) -> np.ndarray:
+        g = torch.Generator().manual_seed(self.seed + epoch)
+        perm = torch.randperm(self.n, generator=g)[: self.per_rank * self.world]
+        return perm[self.rank:: self.world].numpy()
+
+
+class DeviceDataset:
+    """Images (uint8 or fp32 [N,3,Hs,Ws]) and optional region-id maps ([N,Hs,Ws] int64) resident in device memory."""
+
+    def __init__(self, images: torch.Tensor, region_ids: Optional[torch.Tensor] = None, device="cuda"):
+        if images.dim() != 4 or images.shape[1] != 3 or images.dtype not in (torch.uint8, torch.float32):
+            raise ValueError("DeviceDataset: images must be uint8 or float32 [N,3,H,W]")
+        self.images = images.to(device).contiguous()
+        self.region_ids = None if region_ids is None else region_ids.to(device=device, dtype=torch.int64).contiguous()
+        if self.region_ids is not None and tuple(self.region_ids.shape) != (images.shape[0],) + tuple(images.shape[2:]):
+            raise ValueError("DeviceDataset: region_ids must be [N,H,W]")
+
+    def __len__(self):
+        return self.images.shape[0]
+
+    @classmethod
+    def from_file(cls, path: str, device="cuda") -> "DeviceDataset":
+        """A torch.save()d dict {'images': uint8/float32 [N,3,H,W], optional 'region_ids': [N,H,W]} or a bare tensor."""
+        obj = torch.load(path, map_location="cpu")
+        if isinstance(obj, torch.Tensor):
+            return cls(obj, None, device)
+        return cls(obj["images"], obj.get("region_ids"), device)
+
+
+def make_step_batch(ds: DeviceDataset, fg_idx: np.ndarray, bg0_idx: np.ndarray, bg1_idx: np.ndarray, h: int, w: int,
+                    rng: np.random.Generator, foreground_min: float = 0.5, foreground_max: float = 0.8,
+                    id_stride: int = 1, use_regions: bool = True) -> Dict[str, torch.Tensor]:
+    """One training batch with the keyword set of MODEL.forward (main.py:616-628), every tensor made on the device."""
+    dev = ds.images.device
+    n, hs, ws = len(fg_idx), ds.images.shape[2], ds.images.shape[3]
+    out = {}
+    tabs = []
+    for idx in (fg_idx, fg_idx, bg0_idx, bg1_idx):            # query view, key view (same images), two backgrounds
+        tabs.append(crop_table(idx, rrc_params(rng, n, hs, ws), rng.random(n) < 0.5))
+    rects = np.concatenate([erase_params(rng, n, h, w, (foreground_min, foreground_max)) for _ in range(2)])
+    table = torch.from_numpy(np.concatenate(tabs)).to(dev, non_blocking=True)        # one H2D copy per step
+    rects_d = torch.from_numpy(rects).to(dev, non_blocking=True)
+    reg = ds.region_ids if use_regions else None
+    fg = ops.crop_resize_flip(ds.images, reg, table[: 2 * n], h, w, id_stride, want_ids=True)
+    bg = ops.crop_resize_flip(ds.images, None, table[2 * n:], h, w, 1, want_ids=False)
+    ops.erase_rect(bg[0], rects_d)
+    out["img_a"], out["img_b"] = fg[0][:n], fg[0][n:]
+    out["pixel_ids_a"], out["pixel_ids_b"] = fg[1][:n], fg[1][n:]
+    out["region_ids_a"], out["region_ids_b"] = fg[2][:n], fg[2][n:]
+    out["bg0"], out["bg1"] = bg[0][:n], bg[0][n:]
+    return out

@@ -277,13 +277,25 @@ __global__ __launch_bounds__(64 * SM_WAVES) void rowkey_small_kernel(RowKeyArgs 
         }
 
         CP2_STAMP(3);
+        if (a.lnegT && a.ln_sk == 1 && row_ok) {
+            // row-major logits [R][K]: registers 4 g .. 4 g + 3 are four consecutive keys -> one 16-byte store each
+            // (K % 4 == 0, so a quad is valid or invalid as a whole)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int key0 = kbase + 8 * g + 4 * h;
+                if (key0 < a.K) {
+                    const f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(a.lnegT + (int64_t)r * a.ln_sr + key0) = v;
+                }
+            }
+        }
         float sv[16];
         float tmax = -INFINITY;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int key = kbase + rho(reg, h);
             const bool valid = key < a.K;
-            if (a.lnegT && valid && row_ok) a.lnegT[(int64_t)key * a.ln_sk + (int64_t)r * a.ln_sr] = acc[reg];
+            if (a.lnegT && a.ln_sk != 1 && valid && row_ok) a.lnegT[(int64_t)key * a.ln_sk + (int64_t)r * a.ln_sr] = acc[reg];
             sv[reg] = valid ? acc[reg] * a.inv_t : -INFINITY;
             tmax = fmaxf(tmax, sv[reg]);
             cnt += (sv[reg] > pos_s) ? 1 : 0;

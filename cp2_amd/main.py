@@ -4,9 +4,10 @@ Every flag of reference main.py:37-132 is accepted with the same name, type and 
 authors' launch scripts keep working; additive flags are grouped at the end of get_args().
 One process per GPU: either started by torchrun (RANK / LOCAL_RANK / WORLD_SIZE in the env) or,
 as the reference does (main.py:732), spawned here with --world-size N.  Collectives run on RCCL
-(`--dist-backend nccl` is RCCL on ROCm).  Real-image loading (albumentations / cv2 pipelines of
-reference loader.py) is outside this hot path: `--synthetic` feeds on-device batches with the
-loader's output contract.
+(`--dist-backend nccl` is RCCL on ROCm).  Input: `--tensor_dataset FILE` keeps the whole image set in HBM and builds
+every batch on the device (cp2_amd/augment.py: two-crop views with id maps + erased backgrounds, the geometry of
+reference loader.py:50-118 / main.py:204-245); `--synthetic` feeds generated batches with the same contract.
+Decoding image folders (PIL / cv2) and the photometric transforms stay outside this hot path.
 """
 from __future__ import annotations
 
@@ -95,6 +96,9 @@ def get_args(argv=None):
     # ---- additive (not in the reference)
     p.add_argument("--queue_size", default=DEFAULT_QUEUE_SIZE, type=int, help="MoCo queue length K (reference: fixed 65536)")
     p.add_argument("--synthetic", action="store_true", help="on-device synthetic batches (loader contract of SURVEY 8d)")
+    p.add_argument("--tensor_dataset", default="", type=str,
+                   help="torch file {'images': uint8/float32 [N,3,H,W], optional 'region_ids': [N,H,W]}: resident in HBM, "
+                        "augmented on the device (cp2_amd/augment.py)")
     p.add_argument("--steps_per_epoch", default=100, type=int, help="with --synthetic: steps per epoch")
     p.add_argument("--amp", default="bf16", choices=["none", "bf16"], help="encoder autocast dtype")
     p.add_argument("--no_channels_last", action="store_true")
@@ -199,28 +203,49 @@ def main_worker(rank, args):
         wrapped.load_state_dict(ck["state_dict"]) if world > 1 else model.load_state_dict(
             {k.replace("module.", "", 1): v for k, v in ck["state_dict"].items()})
         optimizer.load_state_dict(ck["optimizer"])
-    if not args.synthetic:
-        raise NotImplementedError("only --synthetic input is built in; real-image augmentation (reference loader.py) "
-                                  "is a 'next' row of the scope table (SURVEY 8f-1)")
     per_gpu = args.batch_size // world
+    dataset = None
+    if args.tensor_dataset:
+        from . import augment
+        dataset = augment.DeviceDataset.from_file(args.tensor_dataset, device)
+        # three independently shuffled passes over the same images: foreground pairs, background 0, background 1
+        samplers = [augment.EpochSampler(len(dataset), world, rank, seed) for seed in (0, 1024, 2048)]   # main.py:286-288
+        steps_per_epoch = (len(dataset) // world) // per_gpu
+        if steps_per_epoch < 1:
+            raise ValueError(f"--tensor_dataset holds {len(dataset)} images: fewer than one batch of {args.batch_size}")
+        rng = np.random.default_rng(args.seed + 7919 * rank)
+        use_regions = args.mapping_type in (builder.MappingType.REGION_ID, builder.MappingType.PIXEL_REGION_ID)
+    elif args.synthetic:
+        steps_per_epoch = args.steps_per_epoch
+    else:
+        raise NotImplementedError("give --tensor_dataset FILE (images resident in HBM, augmented on the device) or "
+                                  "--synthetic; decoding image folders (reference datasets/, PIL / cv2) is outside the hot path")
     runner = TrainStep(wrapped, optimizer, use_graph=use_graph)
     step = 0
     for epoch in range(args.start_epoch, args.epochs):
         lr = args.lr if args.remove_lr_scheduler else adjust_learning_rate(optimizer, epoch, args)
         model.train()
         t0, seen = time.time(), 0
-        for i in range(args.steps_per_epoch):
+        if dataset is not None:
+            order = [s.indices(epoch) for s in samplers]
+        for i in range(steps_per_epoch):
             if step > args.max_steps:
                 break
-            batch = synthetic.make_batch(per_gpu, args.img_height, args.img_width, device,
-                                         seed=args.seed + rank + 1000 * step, foreground_min=args.foreground_min,
-                                         foreground_max=args.foreground_max)
+            if dataset is not None:
+                sl = slice(i * per_gpu, (i + 1) * per_gpu)
+                batch = augment.make_step_batch(dataset, order[0][sl], order[1][sl], order[2][sl], args.img_height,
+                                                args.img_width, rng, args.foreground_min, args.foreground_max,
+                                                id_stride=args.pixel_ids_stride, use_regions=use_regions)
+            else:
+                batch = synthetic.make_batch(per_gpu, args.img_height, args.img_width, device,
+                                             seed=args.seed + rank + 1000 * step, foreground_min=args.foreground_min,
+                                             foreground_max=args.foreground_max)
             if args.same_foreground:
                 batch["img_b"], batch["pixel_ids_b"], batch["region_ids_b"] = batch["img_a"], batch["pixel_ids_a"], batch["region_ids_a"]
             loss = runner(batch)
             seen += per_gpu * world
             if i % args.print_freq == 0 and rank == 0:
-                print(f"Epoch: [{epoch}][{i}/{args.steps_per_epoch}] loss {float(loss):.4f} lr {lr:.5f} "
+                print(f"Epoch: [{epoch}][{i}/{steps_per_epoch}] loss {float(loss):.4f} lr {lr:.5f} "
                       f"{seen / (time.time() - t0):.0f} img/s", flush=True)
             step += 1
         model.on_train_epoch_end(step)

@@ -107,6 +107,37 @@ def gather_rows(src: torch.Tensor, idx: torch.Tensor, err_flag: Optional[torch.T
     return dst
 
 
+# ---------------------------------------------------------------- f1: on-device augmentation
+def crop_resize_flip(src: torch.Tensor, src_region: Optional[torch.Tensor], params: torch.Tensor, H: int, W: int,
+                     id_stride: int = 1, want_ids: bool = True):
+    """RandomResizedCrop + HorizontalFlip with explicit parameters (reference loader.py:50-118, main.py:206-216).
+    src: [N,3,Hs,Ws] uint8 / float32 on the GPU; params: int32 [B,8] device table (augment.crop_table).
+    Returns (img [B,3,H,W] f32, pixel_ids [B,H,W] int64 or None, region_ids or None)."""
+    lib = _lib.load()
+    if not src.is_cuda or src.dtype not in (torch.uint8, torch.float32) or src.dim() != 4 or src.shape[1] != 3:
+        raise _lib.Cp2LibraryError("crop_resize_flip: src must be a uint8 / float32 [N,3,Hs,Ws] GPU tensor")
+    N, _, Hs, Ws = src.shape
+    B = params.shape[0]
+    img = torch.empty((B, 3, H, W), dtype=torch.float32, device=src.device)
+    pix = torch.empty((B, H, W), dtype=torch.int64, device=src.device) if want_ids else None
+    reg = torch.empty((B, H, W), dtype=torch.int64, device=src.device) if want_ids else None
+    rc = lib.cp2_crop_resize_flip(_dev(src, "src"), int(src.dtype == torch.uint8), _opt(src_region, "src_region", torch.int64),
+                                  N, Hs, Ws, _dev(params, "params", torch.int32), img.data_ptr(), _opt(pix, "pix"),
+                                  _opt(reg, "reg"), B, H, W, int(id_stride), _stream())
+    _lib.check(rc, "cp2_crop_resize_flip")
+    return img, pix, reg
+
+
+def erase_rect(img: torch.Tensor, rects: torch.Tensor) -> None:
+    """In place RandomErasing(value=0): img[b,:,top:top+h,left:left+w] = 0; rects int32 [B,4] on the GPU (main.py:218-224)."""
+    lib = _lib.load()
+    B, ch, H, W = img.shape
+    if ch != 3 or rects.shape != (B, 4):
+        raise ValueError("erase_rect: img [B,3,H,W] and rects [B,4] expected")
+    rc = lib.cp2_erase_rect(_dev(img, "img", torch.float32), _dev(rects, "rects", torch.int32), B, H, W, _stream())
+    _lib.check(rc, "cp2_erase_rect")
+
+
 # ---------------------------------------------------------------- a3-a5
 def corr_iou(ids_a: torch.Tensor, ids_b: torch.Tensor, mask_a: Optional[torch.Tensor] = None,
              mask_b: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:

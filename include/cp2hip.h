@@ -198,6 +198,21 @@ int cp2_masked_quantiles_multi(int njobs, const float* const* x, const int64_t* 
                                const int* R, const int* N, const float* const* mask_a, const float* const* mask_b,
                                const int* P, const int* want, const float* q, int NQ, float* const* out, void* stream);
 
+/* ---- f1: on-device two-crop augmentation + background erasing --- loader.py:39-43,50-118; main.py:204-225
+ * One launch makes B output samples from a dataset resident in device memory: src [N,3,Hs,Ws] fp32 in [0,1]
+ * (src_is_u8 = 0) or uint8 (src_is_u8 = 1, scaled by 1/255 like ToTensor); src_region [N,Hs,Ws] int64 or NULL.
+ * params: device int32 [B,8] = {source index, crop top, left, height, width, flip, 0, 0} (RandomResizedCrop +
+ * HorizontalFlip parameters drawn by the caller).  out_img [B,3,H,W]: bilinear, half-pixel centres, replicated edges;
+ * out_pix / out_reg [B,H,W] int64 (either may be NULL): nearest neighbour, source cell floor(dst*crop/out); pixel id of
+ * source cell (y,x) = y*Ws + x + 1 at id_stride 1, else the id of the centre tap of its stride block mapped back by
+ * INTER_NEAREST_EXACT (loader.py:66-73); region id = src_region, or the pixel id when src_region is NULL. */
+int cp2_crop_resize_flip(const void* src, int src_is_u8, const int64_t* src_region, int N, int Hs, int Ws,
+                         const int32_t* params, float* out_img, int64_t* out_pix, int64_t* out_reg, int B, int H,
+                         int W, int id_stride, void* stream);
+/* RandomErasing(p=1, value=0) of the background view (main.py:218-224): img[b,:,top:top+h,left:left+w] = 0 exactly;
+ * rects: device int32 [B,4] = {top, left, h, w} (h = 0 skips the sample).  In place. */
+int cp2_erase_rect(float* img, const int32_t* rects, int B, int H, int W, void* stream);
+
 /* ---- optimizer step of the query encoder on the flat parameter buffer ---------------- main.py:467-477, :640-642
  * torch.optim.SGD(momentum, weight_decay) (dampening 0, no Nesterov), bit-identical to torch's default multi-tensor
  * implementation on the same GPU:  g' = g + wd*p;  buf = buf*momentum + g';  p = p - lr*buf.

@@ -406,3 +406,56 @@ def densecl_local_loss(q_embed, k_embed, q_local, k_local, q_pixel_ids, k_pixel_
 def queue_infonce(rows, pos, queue, temperature):
     """The rows-vs-queue InfoNCE on its own (T19): mean_r [lse_r - pos_r/T]."""
     return contrastive_head(pos.reshape(-1, 1), rows @ queue, temperature)
+
+
+# --------------------------------------------------------------------------
+# f1: two-crop augmentation with explicit parameters   loader.py:39-43,50-118; main.py:204-225
+# --------------------------------------------------------------------------
+def pixel_id_map(hs: int, ws: int, stride: int = 1) -> np.ndarray:
+    """loader.py:66-73: arange(1 .. H*W) -> rescale_ids(stride) (centre taps) -> resized back to (H, W) with
+    INTER_NEAREST_EXACT, whose published rule is  source = floor((dst + 0.5) * small / big)."""
+    ids = np.arange(1, hs * ws + 1, dtype=np.int64).reshape(hs, ws)
+    if stride <= 1:
+        return ids
+    small = ids[stride // 2:: stride, stride // 2:: stride]
+    yi = ((2 * np.arange(hs) + 1) * small.shape[0]) // (2 * hs)
+    xi = ((2 * np.arange(ws) + 1) * small.shape[1]) // (2 * ws)
+    return small[yi][:, xi]
+
+
+def crop_resize_flip(src: np.ndarray, region: Optional[np.ndarray], box, flip: bool, h: int, w: int, id_stride: int = 1):
+    """One sample.  src: (3, Hs, Ws) float32 in [0,1]; box = (top, left, ch, cw).  Image: bilinear with half-pixel
+    centres and replicated edges, every product / sum rounded to fp32 in the kernel's order; ids: nearest neighbour,
+    source cell floor(dst * crop / out); then the horizontal flip of both."""
+    top, left, ch, cw = [int(v) for v in box]
+    hs, ws = src.shape[1:]
+    f32 = np.float32
+    ys, xs = np.arange(h), np.arange(w)
+    xr = (w - 1 - xs) if flip else xs
+    sy = top + (ys * ch) // h
+    sx = left + (xr * cw) // w
+    pid_map = pixel_id_map(hs, ws, id_stride)
+    pix = pid_map[sy][:, sx]
+    reg = region[sy][:, sx] if region is not None else pix
+    fy = (ys.astype(f32) + f32(0.5)) * (f32(ch) / f32(h)) - f32(0.5)
+    fx = (xr.astype(f32) + f32(0.5)) * (f32(cw) / f32(w)) - f32(0.5)
+    cy = np.minimum(np.maximum(fy, f32(0)), f32(ch - 1)).astype(f32)
+    cx = np.minimum(np.maximum(fx, f32(0)), f32(cw - 1)).astype(f32)
+    y0, x0 = np.floor(cy).astype(np.int64), np.floor(cx).astype(np.int64)
+    y1, x1 = np.minimum(y0 + 1, ch - 1), np.minimum(x0 + 1, cw - 1)
+    wy, wx = (cy - y0.astype(f32)).astype(f32)[:, None], (cx - x0.astype(f32)).astype(f32)[None, :]
+    s = src.astype(f32)
+    g = lambda yy, xx: s[:, top + yy][:, :, left + xx]          # noqa: E731
+    one = f32(1.0)
+    r0 = (g(y0, x0) * (one - wx)).astype(f32) + (g(y0, x1) * wx).astype(f32)
+    r1 = (g(y1, x0) * (one - wx)).astype(f32) + (g(y1, x1) * wx).astype(f32)
+    img = (r0.astype(f32) * (one - wy)).astype(f32) + (r1.astype(f32) * wy).astype(f32)
+    return img.astype(f32), pix, reg
+
+
+def erase_rect(img: np.ndarray, rect) -> np.ndarray:
+    """RandomErasing(value=0) of one sample (3, H, W): exact zeros in the rectangle (main.py:218-224)."""
+    top, left, hh, ww = [int(v) for v in rect]
+    out = img.copy()
+    out[:, top:top + hh, left:left + ww] = 0.0
+    return out

@@ -41,3 +41,24 @@ def test_main_cli_synthetic_and_checkpoint(tmp_path):
     assert not unexpected and all("conv_seg" in k for k in missing)
     assert all(torch.isfinite(v).all() for v in enc.values() if v.dtype.is_floating_point)
     assert len(ck["optimizer"]["state"]) > 20
+
+
+@pytest.mark.timeout(600)
+def test_main_cli_tensor_dataset_on_device_augmentation(tmp_path):
+    """`cp2_amd.main` without --synthetic: a uint8 image set with region maps stays in HBM, every batch is
+    cropped / flipped / erased on the device; PROPOSED weights so the region ids are consumed, pixel ids at stride 2."""
+    g = torch.Generator().manual_seed(0)
+    n = 48
+    torch.save({"images": torch.randint(1, 256, (n, 3, 80, 96), dtype=torch.uint8, generator=g),
+                "region_ids": torch.randint(0, 12, (n, 80, 96), generator=g)}, tmp_path / "ds.pt")
+    cmd = [sys.executable, "-m", "cp2_amd.main", "--config", os.path.join(ROOT, "configs", "config_pretrain_r18.py"),
+           "--run_id", "d", "--log_dir", str(tmp_path), "--tensor_dataset", str(tmp_path / "ds.pt"), "--pretrain_from_scratch",
+           "--queue_size", "256", "--img_height", "64", "--img_width", "64", "-b", "8", "--epochs", "2", "--lr", "0.01",
+           "--dist-url", "tcp://127.0.0.1:29534", "--print-freq", "1", "--pretrain_type", "PROPOSED", "--mapping_type",
+           "PIXEL_REGION_ID", "--lmbd_pixel_corr_weight", "3", "--lmbd_region_corr_weight", "2", "--pixel_ids_stride", "2",
+           "--negative_type", "AVERAGE"]
+    res = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=550)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert "Epoch: [1][5/6]" in res.stdout                       # 48 images / batch 8 = 6 steps per epoch
+    ck = torch.load(tmp_path / "d" / "checkpoint.ckpt", map_location="cpu", weights_only=False)
+    assert ck["epoch"] == 2 and ck["pretrain_type"] == "PROPOSED" and int(ck["state_dict"]["module.queue_ptr"]) == (12 * 8) % 256
