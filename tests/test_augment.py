@@ -133,8 +133,8 @@ def test_step_batch_contract_and_model_step():
         frac = zero.float().mean((1, 2))
         assert (frac > 0.45).all() and (frac < 0.85).all()       # RandomErasing scale (0.5, 0.8); source pixels are >= 1/255
         assert torch.equal(zero, batch[k][:, 0] == 0)            # the mask rule of builder.py:1146 sees the same rectangle
-    iou, _ = ops.corr_iou(ops.strided_gather(batch["pixel_ids_a"], 16), ops.strided_gather(batch["pixel_ids_b"], 16))
-    assert float(iou.max()) > 0                                  # two crops of one image overlap somewhere
+    iou, _ = ops.corr_iou(batch["pixel_ids_a"], batch["pixel_ids_b"])      # full-resolution maps (P = 4096)
+    assert float(iou.max()) > 0                                  # two crops of one image share source pixels somewhere
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cfg = Config.fromfile(os.path.join(root, "configs", "config_pretrain_r18.py"))
     model = builder.MODEL(cfg, rank=0, K=256, pretrain_from_scratch=True, pretrain_type=PretrainType.CP2, device="cuda").cuda().train()
