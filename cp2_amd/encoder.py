@@ -169,7 +169,18 @@ class Conv2d(nn.Conv2d):
         w = self.shadow_weight
         if w is not None and x.dtype == torch.bfloat16:
             ext = _cext.load() if Conv2d.cpp_nodes else None
-            if (Conv2d.gemm_1x1 and self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0)
+            stride1 = self.stride == (1, 1)
+            if (not stride1 and self.kernel_size == (1, 1) and self.padding == (0, 0) and self.groups == 1 and x.dim() == 4
+                    and (Conv2d.graph_step or torch.cuda.is_current_stream_capturing())
+                    and torch.is_grad_enabled() and self.weight.requires_grad):
+                # A strided 1x1 convolution (the ResNet down-sample branches) is the stride-1 one on the sub-sampled
+                # input.  Used when the step is captured into a hipGraph: every 1x1 weight gradient then comes from
+                # cp2_wgrad1x1 and none from MIOpen's zero-fill + atomic-add solvers (ConvHipImplicitGemmGroupWrwXdlops,
+                # ConvAsmImplicitGemmGTCDynamicWrwXdlopsNHWC), whose results went non-finite from the second replay on
+                # (tools/graph_fault_probe.py).
+                x = x[:, :, ::self.stride[0], ::self.stride[1]].contiguous(memory_format=torch.channels_last)
+                stride1 = True
+            if (Conv2d.gemm_1x1 and self.kernel_size == (1, 1) and stride1 and self.padding == (0, 0)
                     and self.groups == 1 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
                 m, ci, co = x.shape[0] * x.shape[2] * x.shape[3], self.in_channels, self.out_channels
                 mm_fwd = m <= 32768 and ci * co >= 131072
@@ -186,6 +197,8 @@ class Conv2d(nn.Conv2d):
             if self.weight.requires_grad and torch.is_grad_enabled():
                 w = ext.shadow_weight(self.weight, w) if ext is not None else _ShadowWeightFn.apply(self.weight, w)
             b = self.bias.to(torch.bfloat16) if self.bias is not None else None
+            if stride1 and self.stride != (1, 1):               # sub-sampled above, but the GEMM route did not take it
+                return F.conv2d(x, w, b)
             return self._conv_forward(x, w, b)
         return super().forward(x)
 

@@ -71,9 +71,14 @@ class TrainStep:
     weight-gradient solvers have been seen to return garbage under replay).  On disagreement, or
     if the capture itself fails, the state is rolled back and the step continues eagerly (`self.fallback_reason`)."""
 
-    def __init__(self, model, optimizer, use_graph: bool = False, warmup_steps: int = 3, verify: bool = True):
+    def __init__(self, model, optimizer, use_graph: bool = False, warmup_steps: int = 3, verify: bool = True,
+                 reverify_every: int = 200):
         self.model, self.optimizer = model, optimizer
         self.use_graph, self.warmup_steps, self.verify = use_graph, warmup_steps, verify
+        # the replay fault of DESIGN.md section 5 depends on what the graph's memory pool holds, so a replay that was
+        # right once can go wrong later: with verify on, every `reverify_every`-th replay is checked again
+        self.reverify_every = reverify_every
+        self._replays = 0
         self.fallback_reason = None
         if use_graph:
             # libraries initialise per shape on first use (hipBLASLt refuses to do that while a stream is capturing): the
@@ -128,9 +133,25 @@ class TrainStep:
         for k in INPUT_KEYS:
             self.static[k].copy_(batch[k])
         self.static_idx.copy_(self._shuffle_index(n_all, dev))
+        self._replays += 1
+        if self.verify and self.reverify_every and self._replays % self.reverify_every == 0:
+            return self._checked_replay(batch)
         self.graph.replay()
+        self._after_replay()
         self.step_idx += 1
         return self.static_loss
+
+    def _after_replay(self):
+        """Host-side bookkeeping the captured code did once, at capture time: per-step log record, IoU lists, BatchNorm
+        batch counters (reference builder.py:1254-1257,1553-1604; torch.nn.BatchNorm2d.num_batches_tracked)."""
+        inner = self._inner()
+        if getattr(self, "_log_template", None) is not None:
+            step0, n, names, vals = self._log_template
+            inner._pending_logs.append((self.step_idx, n, names, vals.clone()))
+        for src, dst in getattr(self, "_iou_templates", ()):
+            dst.append(src.clone())
+        for m in getattr(self, "_bn_modules", ()):
+            m._pending_batches += 1
 
     # ------------------------------------------------------------------ capture, checked against an eager step
     def _snapshot(self):
@@ -171,20 +192,9 @@ class TrainStep:
         ref_grads = ref_loss = None
         snap = None
         if self.verify:
-            side = torch.cuda.Stream()                         # like the warm-up steps: keep the capture's origin stream idle
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                snap = self._snapshot()
-                loss = self.model(visualize=False, step=self.step_idx, new_epoch=False, idx_shuffle=self.static_idx, **self.static)
-                self.optimizer.zero_grad(set_to_none=True)
-                loss.backward()
-                ref_loss = loss.detach().clone()
-                ref_grads = [None if p.grad is None else p.grad.detach().clone() for p in params]
-                del loss
-                self._restore(snap, optimizer_too=False)      # the eager probe advanced EMA / BN statistics / queue
-                self.optimizer.zero_grad(set_to_none=True)
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
+            snap, ref_loss, ref_grads = self._eager_probe(params)
+        n_logs, n_iou = len(inner._pending_logs), len(inner.correlation_ious)
+        bn_before = {m: m._pending_batches for m in inner.modules() if hasattr(m, "_pending_batches")}
         graph = torch.cuda.CUDAGraph()
         self.optimizer.zero_grad(set_to_none=True)
         try:
@@ -195,21 +205,73 @@ class TrainStep:
                 self._restore(snap, optimizer_too=False)        # a capture executes nothing, but host-side lists grew
             return self._give_up_graph(f"capture failed: {type(err).__name__}: {err}", batch)
         self.graph = graph
+        # what the captured python code appended once is what every replay has to append again (meters and
+        # IoU lists saw one record per flush in graph mode, BN batch counters stalled)
+        self._log_template = inner._pending_logs[n_logs] if len(inner._pending_logs) > n_logs else None
+        self._iou_templates = []
+        if len(inner.correlation_ious) > n_iou:
+            self._iou_templates = [(inner.correlation_ious[n_iou], inner.correlation_ious),
+                                   (inner.masked_correlation_ious[n_iou], inner.masked_correlation_ious)]
+        self._bn_modules = [m for m, b in bn_before.items() if m._pending_batches != b]
+        del inner._pending_logs[n_logs:], inner.correlation_ious[n_iou:], inner.masked_correlation_ious[n_iou:]
+        for m, b in bn_before.items():
+            m._pending_batches = b                              # a captured call executes nothing
         self.graph.replay()
         if self.verify:
-            bad = None
-            if not bool(torch.isfinite(self.static_loss)) or abs(float(self.static_loss) - float(ref_loss)) > 2e-2 * max(1.0, abs(float(ref_loss))):
-                bad = f"loss {float(self.static_loss):.5f} vs eager {float(ref_loss):.5f}"
-            for p, g in zip(params, ref_grads):
-                if bad or g is None or p.grad is None:
-                    continue
-                a, b = p.grad.float(), g.float()
-                den = float(b.norm())
-                err = float((a - b).norm())
-                if not (err == err) or err > 0.2 * den + 1e-6:
-                    bad = f"gradient of a {tuple(p.shape)} parameter: |replay - eager| = {err:.3e}, |eager| = {den:.3e}"
+            bad = self._compare(params, ref_loss, ref_grads)
             if bad:
                 self._restore(snap, optimizer_too=True)
                 return self._give_up_graph("replayed gradients differ from eager: " + bad, batch)
+        self._after_replay()
+        self.step_idx += 1
+        return self.static_loss
+
+    def _eager_probe(self, params):
+        """One eager forward / backward on the static batch from the current state (on a side stream: a backward on the
+        stream a capture later starts from made hipStreamEndCapture fail), then the state is put back."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            snap = self._snapshot()
+            loss = self.model(visualize=False, step=self.step_idx, new_epoch=False, idx_shuffle=self.static_idx, **self.static)
+            self.optimizer.zero_grad(set_to_none=True)
+            loss.backward()
+            ref_loss = loss.detach().clone()
+            ref_grads = [None if p.grad is None else p.grad.detach().clone() for p in params]
+            del loss
+            self._restore(snap, optimizer_too=False)          # the eager probe advanced EMA / BN statistics / queue
+            self.optimizer.zero_grad(set_to_none=True)
+            inner = self._inner()
+            if hasattr(inner, "_refresh_query_shadow"):        # load_state_dict bumped every parameter version: rebuild the
+                inner._refresh_query_shadow()                  # bf16 image here, not inside the captured forward
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        return snap, ref_loss, ref_grads
+
+    def _compare(self, params, ref_loss, ref_grads):
+        """None if the replay agrees with the eager probe.  Per tensor: relative L2 error <= 5e-2 (bf16 encoders with
+        atomically accumulated MIOpen weight gradients differ by ~1e-2 between two eager runs) and no element further
+        than 0.25 max|g| from the eager value; non-finite anywhere fails."""
+        if not bool(torch.isfinite(self.static_loss)) or abs(float(self.static_loss) - float(ref_loss)) > 2e-2 * max(1.0, abs(float(ref_loss))):
+            return f"loss {float(self.static_loss):.5f} vs eager {float(ref_loss):.5f}"
+        for p, g in zip(params, ref_grads):
+            if g is None or p.grad is None:
+                continue
+            a, b = p.grad.float(), g.float()
+            den, err, amax = float(b.norm()), float((a - b).norm()), float((a - b).abs().max())
+            if not (err == err) or err > 5e-2 * den + 1e-6 or amax > 0.25 * float(b.abs().max()) + 1e-6:
+                return f"gradient of a {tuple(p.shape)} parameter: |replay - eager| = {err:.3e}, |eager| = {den:.3e}, max |diff| = {amax:.3e}"
+        return None
+
+    def _checked_replay(self, batch):
+        inner = self._inner()
+        params = [p for p in inner.parameters() if p.requires_grad]
+        snap, ref_loss, ref_grads = self._eager_probe(params)
+        self.graph.replay()
+        bad = self._compare(params, ref_loss, ref_grads)
+        if bad:
+            self._restore(snap, optimizer_too=True)
+            return self._give_up_graph(f"replay {self._replays} differs from eager: " + bad, batch)
+        self._after_replay()
         self.step_idx += 1
         return self.static_loss

@@ -192,8 +192,9 @@ def main_worker(rank, args):
     wrapped = model
     if world > 1:
         # queue / BN buffers are updated identically on every rank, so the per-forward buffer
-        # broadcast of the reference's default DDP is dropped; conv_seg is frozen, so
-        # no unused-parameter search is needed either.
+        # broadcast of the reference's default DDP is dropped; every parameter the chosen
+        # path never uses is frozen in builder.MODEL (conv_seg on the contrast path, the segmentation head
+        # and the unselected neck heads for DENSECL / PROPOSED_V2), so no unused-parameter search either.
         wrapped = DistributedDataParallel(model, device_ids=[local], output_device=local, broadcast_buffers=False,
                                           gradient_as_bucket_view=True)
     optimizer = make_optimizer([p for p in model.parameters()], args, device, capturable=use_graph, model=model)
@@ -203,6 +204,10 @@ def main_worker(rank, args):
         wrapped.load_state_dict(ck["state_dict"]) if world > 1 else model.load_state_dict(
             {k.replace("module.", "", 1): v for k, v in ck["state_dict"].items()})
         optimizer.load_state_dict(ck["optimizer"])
+        if use_graph:      # a checkpoint written by an eager run holds the learning rate as a float: the captured
+            for g in optimizer.param_groups:                   # update must read it from device memory (LR schedule)
+                if not isinstance(g["lr"], torch.Tensor):
+                    g["lr"] = torch.tensor(float(g["lr"]), device=device)
     per_gpu = args.batch_size // world
     dataset = None
     if args.tensor_dataset:
