@@ -115,22 +115,28 @@ class _QueueInfoNCEFn(torch.autograd.Function):
     :762-772 or :866-873): one fused kernel pass, gradients for rows and positives produced in forward."""
 
     @staticmethod
-    def forward(ctx, rows, pos, queue, temperature, layout, R):
+    def forward(ctx, rows, pos, queue, temperature, layout, R, stats):
         need = rows.requires_grad or pos.requires_grad
         res = ops.rowkey_infonce(rows, layout, R, queue, pos.reshape(R, 1).contiguous(), temperature,
-                                 grad_scale=(1.0 / R) if need else None)
+                                 grad_scale=(1.0 / R) if need else None, want_lneg=stats is not None,
+                                 lneg_row_major=stats is not None)
         if need:
             ctx.save_for_backward(res.drows, res.dE.reshape(pos.shape))
+        if stats is not None:       # reference builder.py:776-786 / :876-886: mean and quartiles of every row's negatives
+            K = queue.shape[1]
+            stats["neg_mean"] = res.lneg.mean(1)
+            stats["neg_quartiles"] = ops.masked_quantiles(res.lneg, K, 1, R, K)
         return res.loss
 
     @staticmethod
     def backward(ctx, g):
         drows, dpos = ctx.saved_tensors
-        return drows * g, dpos * g, None, None, None, None
+        return drows * g, dpos * g, None, None, None, None, None
 
 
-def queue_infonce(rows: torch.Tensor, pos: torch.Tensor, queue: torch.Tensor, temperature: float) -> torch.Tensor:
-    """rows: [R,C] (one vector per row) or [b,C,S2] (one vector per pixel, reference layout); pos: R positives."""
+def queue_infonce(rows: torch.Tensor, pos: torch.Tensor, queue: torch.Tensor, temperature: float, stats=None) -> torch.Tensor:
+    """rows: [R,C] (one vector per row) or [b,C,S2] (one vector per pixel, reference layout); pos: R positives.
+    stats: None, or a dict that receives 'neg_mean' [R] and 'neg_quartiles' [3,R] of the raw queue logits (logging)."""
     rows = rows.float().contiguous()
     if rows.dim() == 2:
         R, C = rows.shape
@@ -138,10 +144,10 @@ def queue_infonce(rows: torch.Tensor, pos: torch.Tensor, queue: torch.Tensor, te
     else:
         b, C, S2 = rows.shape
         R, layout = b * S2, (S2, C * S2, 1, S2)
-    return _QueueInfoNCEFn.apply(rows, pos.float(), queue, float(temperature), layout, R)
+    return _QueueInfoNCEFn.apply(rows, pos.float(), queue, float(temperature), layout, R, stats)
 
 
-def densecl_local_positives(q_embed, k_embed, q_local, k_local, ids_q, ids_k, lmbd_coordinate: float = 0.0):
+def densecl_local_positives(q_embed, k_embed, q_local, k_local, ids_q, ids_k, lmbd_coordinate: float = 0.0, metrics=None):
     """Positive score of every query pixel for the DenseCL local loss (reference builder.py:818-855):
     local similarity with the key pixel that maximises the BACKBONE similarity; where the two id maps overlap it is
     mixed with the summed local similarity over id-matching key pixels.  Inputs are channel-normalised (b, C, S2);
@@ -149,11 +155,18 @@ def densecl_local_positives(q_embed, k_embed, q_local, k_local, ids_q, ids_k, lm
     best = torch.bmm(q_embed.transpose(1, 2), k_embed).argmax(dim=2)
     local_sim = torch.bmm(q_local.transpose(1, 2), k_local)
     pos = torch.gather(local_sim, 2, best.unsqueeze(2)).squeeze(2)
-    if lmbd_coordinate > 0:
+    if lmbd_coordinate > 0 or metrics is not None:
         corr = ids_q[:, :, None] == ids_k[:, None, :]
         overlap = corr.any(-1)
+    if lmbd_coordinate > 0:
         coord = (local_sim * corr).sum(-1)
         pos = torch.where(overlap, pos * (1 - lmbd_coordinate) + coord * lmbd_coordinate, pos)
+    if metrics is not None:
+        # builder.py:856-864: how often the best local match is the coordinate match (over overlapping pixels; -1: none)
+        hit = (corr.float().argmax(2) == local_sim.argmax(2)) & overlap
+        n_ov = overlap.sum()
+        metrics["matching_positives_rate"] = torch.where(n_ov > 0, hit.sum().float() / n_ov.clamp(min=1).float(),
+                                                          torch.full((), -1.0, device=pos.device))
     return pos, best
 
 
@@ -523,7 +536,10 @@ class MODEL(nn.Module):
                 "train/acc_seg_step": out.acc_dense,
                 "train/+ive_scores_step": out.dense_sample[:, 3].mean(),
                 "train/-ive_scores_step": out.dense_sample[:, 4].mean(),
-                "step/instance_average_positive_scores": out.instance_pos.mean()}
+                "step/instance_average_positive_scores": out.instance_pos.mean(),
+                # builder.py:1265,1282: spread of the pooled foreground vectors over the batch (unbiased std, channel mean)
+                "train/cross_image_variance_source_step": out.q_pos.std(0).mean(),
+                "train/cross_image_variance_target_step": out.k_pos.std(0).mean()}
         if self.log_quartiles:           # same scalar names as the reference's wandb.log (builder.py:1589-1601)
             pq, nq, iq = out.dense_pos_quartiles.mean(1), out.dense_neg_quartiles.mean(1), out.instance_neg_quartiles.mean(1)
             logs.update({"step/dense_per_sample_average_positive_scores": logs["train/+ive_scores_step"],
@@ -569,16 +585,41 @@ class MODEL(nn.Module):
                      F.normalize(glob, dim=1), F.normalize(out["x_avgpool_local_proj"], dim=1))
             return tuple(self._batch_unshuffle_ddp(f, idx_un) for f in feats)
 
-        def global_loss(qg, kg):
-            return queue_infonce(qg, (qg * kg).sum(1), self.queue, self.temp_global)
+        # rank 0 logs the score statistics of the FIRST pass (reference builder.py:774-804, 875-904: log_metrics=True there only)
+        extra = {} if (self.rank == 0 and self.log_quartiles) else None
 
-        def local_loss(q_embed, k_embed, q_local, k_local, ids_q, ids_k):
-            pos, _ = densecl_local_positives(q_embed, k_embed, q_local, k_local, ids_q, ids_k, self.lmbd_coordinate)
-            return queue_infonce(q_local, pos.reshape(-1), self.queue2, self.temp_local)
+        def global_loss(qg, kg, log=False):
+            st = {} if (log and extra is not None) else None
+            pos = (qg * kg).sum(1)
+            loss = queue_infonce(qg, pos, self.queue, self.temp_global, stats=st)
+            if st is not None:
+                nq = st["neg_quartiles"].mean(1)
+                extra.update({"step/instance_average_positive_scores": pos.detach().mean(),
+                              "step/instance_average_negative_scores": st["neg_mean"].mean(),
+                              "step/instance_lower_negative_scores": nq[0], "step/instance_median_negative_scores": nq[1],
+                              "step/instance_upper_negative_scores": nq[2],
+                              "step/cross_image_variance_source_step": qg.detach().std(0).mean(),
+                              "step/cross_image_variance_target_step": kg.std(0).mean()})
+            return loss
+
+        def local_loss(q_embed, k_embed, q_local, k_local, ids_q, ids_k, log=False):
+            st = {} if (log and extra is not None) else None
+            pos, _ = densecl_local_positives(q_embed, k_embed, q_local, k_local, ids_q, ids_k, self.lmbd_coordinate, metrics=st)
+            loss = queue_infonce(q_local, pos.reshape(-1), self.queue2, self.temp_local, stats=st)
+            if st is not None:
+                nq = st["neg_quartiles"].mean(1)
+                iou, _ = ops.corr_iou(ids_q, ids_k)
+                extra.update({"step/dense_average_positive_scores": pos.detach().mean(),
+                              "step/dense_average_negative_scores": st["neg_mean"].mean(),
+                              "step/dense_lower_negative_scores": nq[0], "step/dense_median_negative_scores": nq[1],
+                              "step/dense_upper_negative_scores": nq[2], "step/average_iou": iou.mean(),
+                              "step/non_zero_iou_ratio": (iou != 0).float().mean(),
+                              "step/matching_positives_rate": st["matching_positives_rate"]})
+            return loss
 
         eq, lq, gq = query_features(img_a)
         ek, lk, gk, pooled_k = key_features(img_b)
-        loss_global, loss_local = global_loss(gq, gk), local_loss(eq, ek, lq, lk, pix_a, pix_b)
+        loss_global, loss_local = global_loss(gq, gk, log=True), local_loss(eq, ek, lq, lk, pix_a, pix_b, log=True)
         update = (gk, pooled_k)
         if self.use_symmetrical_loss:
             eq2, lq2, gq2 = query_features(img_b)
@@ -590,8 +631,11 @@ class MODEL(nn.Module):
         loss = (1 - self.lmbd_dense_loss) * loss_global + self.lmbd_dense_loss * loss_local
         self._dequeue_and_enqueue(update[0])
         self._dequeue_and_enqueue2(update[1])
-        self._log_step(step, b, {"train/loss_step": loss.detach(), "train/loss_ins_step": loss_global.detach(),
-                                 "train/loss_dense_step": loss_local.detach()})
+        logs = {"train/loss_step": loss.detach(), "train/loss_ins_step": loss_global.detach(),
+                "train/loss_dense_step": loss_local.detach()}
+        if extra:
+            logs.update(extra)
+        self._log_step(step, b, logs)
         return loss
 
     # ------------------------------------------------------------------ logging without per-step host syncs
@@ -609,7 +653,9 @@ class MODEL(nn.Module):
         vals = torch.stack([p[3] for p in self._pending_logs]).cpu().tolist() if \
             len({len(p[2]) for p in self._pending_logs}) == 1 else [p[3].cpu().tolist() for p in self._pending_logs]
         meters = {"train/loss_step": self.loss_o, "train/loss_ins_step": self.loss_i, "train/loss_dense_step": self.loss_d,
-                  "train/acc_ins_step": self.acc_ins, "train/acc_seg_step": self.acc_seg}
+                  "train/acc_ins_step": self.acc_ins, "train/acc_seg_step": self.acc_seg,
+                  "train/cross_image_variance_source_step": self.cross_image_variance_source,
+                  "train/cross_image_variance_target_step": self.cross_image_variance_target}
         out = []
         for (step, n, names, _), row in zip(self._pending_logs, vals):
             rec = dict(zip(names, row))
