@@ -249,17 +249,21 @@ class TrainStep:
         return snap, ref_loss, ref_grads
 
     def _compare(self, params, ref_loss, ref_grads):
-        """None if the replay agrees with the eager probe.  Per tensor: relative L2 error <= 5e-2 (bf16 encoders with
+        """None if the replay agrees with the eager probe.  Per tensor: L2 error <= 5e-2 |g| (bf16 encoders with
         atomically accumulated MIOpen weight gradients differ by ~1e-2 between two eager runs) and no element further
-        than 0.25 max|g| from the eager value; non-finite anywhere fails."""
+        than 0.25 max|g| from the eager value, both with a floor of 5e-4 of the whole gradient's norm; non-finite
+        anywhere fails.  (Round 1 accepted 0.2 |g|, which only caught garbage.)"""
         if not bool(torch.isfinite(self.static_loss)) or abs(float(self.static_loss) - float(ref_loss)) > 2e-2 * max(1.0, abs(float(ref_loss))):
             return f"loss {float(self.static_loss):.5f} vs eager {float(ref_loss):.5f}"
+        # a few gradients (the first BatchNorm's bias) are sums that cancel to ~1e-3 of the others: their run-to-run
+        # noise is set by the size of the terms, not of the result, hence the floor relative to the whole gradient
+        total = float(torch.sqrt(sum((g.float() ** 2).sum() for g in ref_grads if g is not None)))
         for p, g in zip(params, ref_grads):
             if g is None or p.grad is None:
                 continue
             a, b = p.grad.float(), g.float()
             den, err, amax = float(b.norm()), float((a - b).norm()), float((a - b).abs().max())
-            if not (err == err) or err > 5e-2 * den + 1e-6 or amax > 0.25 * float(b.abs().max()) + 1e-6:
+            if not (err == err) or err > max(5e-2 * den, 5e-4 * total) + 1e-6 or amax > max(0.25 * float(b.abs().max()), 5e-4 * total) + 1e-6:
                 return f"gradient of a {tuple(p.shape)} parameter: |replay - eager| = {err:.3e}, |eager| = {den:.3e}, max |diff| = {amax:.3e}"
         return None
 
