@@ -320,8 +320,11 @@ __global__ __launch_bounds__(256) void keys_split_kernel(const float* __restrict
         if (k0 + j < K) {
             __bf16 hi, lo;
             split_bf(v, hi, lo);
-            qh[(int64_t)c * K + k0 + j] = hi;
-            ql[(int64_t)c * K + k0 + j] = lo;
+            // channel-major image: every 16-key block in the order [0-3, 8-11, 4-7, 12-15] (bits 2 and 3 of the key index
+            // swapped) = the row order of the 32x32 accumulator, so 8 consecutive stored keys are one MFMA fragment
+            const int js = (j & ~12) | ((j & 4) << 1) | ((j & 8) >> 1);
+            qh[(int64_t)c * K + k0 + js] = hi;
+            ql[(int64_t)c * K + k0 + js] = lo;
         }
     }
     __syncthreads();
@@ -718,17 +721,17 @@ CP2_API int cp2_rowkey_infonce_fwd(const float* rows, int RP, int64_t r_sn, int6
     const bool wu = part_U != nullptr;
     if (precision == 1 && WR == 4) {   // split-bf16 on the matrix cores (many-row case only; otherwise the f32 kernel)
         __bf16* ks = static_cast<__bf16*>(keys_split);
-        const bool pre = ks != nullptr && K % 8 == 0 && kps % 8 == 0 && cp2_aligned16(ks);
-        if (pre) {
+        const bool pre = ks != nullptr && K % 16 == 0 && K <= (1 << 20) && cp2_aligned16(ks);
+        if (pre) {      // the queue's hi / lo split once per call, then the LDS-DMA double-buffered kernel (rowkey_bf16x3.hip)
             hipLaunchKernelGGL(keys_split_kernel, dim3(cp2_cdiv(K, 64)), dim3(256), 0, cp2_stream(stream), keys, K, ks);
             int rc0 = cp2_launch_status();
             if (rc0) return rc0;
+            return rowkey_bf16x3_dma_launch(a, ks, grid, wu, cp2_stream(stream));
         }
-        auto kfn = pre ? (wu ? rowkey_fwd_bf16x3_kernel<true, true> : rowkey_fwd_bf16x3_kernel<false, true>)
-                       : (wu ? rowkey_fwd_bf16x3_kernel<true, false> : rowkey_fwd_bf16x3_kernel<false, false>);
+        auto kfn = wu ? rowkey_fwd_bf16x3_kernel<true, false> : rowkey_fwd_bf16x3_kernel<false, false>;
         hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, BF_LDS);
         if (e_ != hipSuccess) return (int)e_;
-        CP2_LAUNCH_PROFILED(kfn, grid, block, BF_LDS, cp2_stream(stream), a, pre ? ks : nullptr);
+        CP2_LAUNCH_PROFILED(kfn, grid, block, BF_LDS, cp2_stream(stream), a, (const __bf16*)nullptr);
         return cp2_launch_status();
     }
 #define CP2_LAUNCH_RK(wr_, wk_, wu_)                                                                            \

@@ -34,3 +34,6 @@ struct RowKeyFinArgs {
 int rowkey_small_num_splits(int K, int* tiles_per_wg);
 int rowkey_small_launch(const RowKeyArgs& a, int nsplit, bool with_u, hipStream_t stream);
 int rowkey_small_finalize_launch(const RowKeyFinArgs& a, float* loss_mean, hipStream_t stream);
+
+// Many-rows split-bf16 form with LDS-DMA double buffering (rowkey_bf16x3.hip); ksplit = the four arrays keys_split_kernel writes
+int rowkey_bf16x3_dma_launch(const RowKeyArgs& a, const void* ksplit, dim3 grid, bool with_u, hipStream_t stream);
