@@ -18,7 +18,7 @@ ma = (torch.rand(B, P, device=dev, generator=g) > 0.4).float(); mb = (torch.rand
 for _ in range(3):
     fw = ops.dense_infonce_fwd(qd, kd, ma, mb, 1.0)
     ops.dense_infonce_bwd(qd, kd, ma, mb, 1.0, fw, 0.2 / B)
-l = torch.randn(K, 32, device=dev, generator=g)
+l = torch.randn(32, K, device=dev, generator=g)
 for _ in range(3):
-    ops.masked_quantiles(l, 1, 32, 32, K)
+    ops.masked_quantiles(l, K, 1, 32, K)
 torch.cuda.synchronize()
