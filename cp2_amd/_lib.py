@@ -50,6 +50,9 @@ SIGNATURES = {
     "cp2_bn_bwd": [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, _P],
     "cp2_masked_quantiles": [_P, c_int64, c_int64, c_int, c_int, _P, _P, c_int, c_int, _P, c_int, _P, _P],
     "cp2_masked_quantiles_multi": [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P],
+    "cp2_cutpaste": [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
+    "cp2_mirror_loss_num_partials": [c_int, c_int64],
+    "cp2_mirror_loss": [_P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int64, _P],
     "cp2_dense_infonce_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, _P, _P, c_float,
                               _P, _P, c_int, c_float, _P, c_int, c_int, c_int, _P],
 }

@@ -652,3 +652,74 @@ def wgrad1x1(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     rc = lib.cp2_wgrad1x1(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), part.data_ptr(), M, CO, CI, _stream())
     _lib.check(rc, "cp2_wgrad1x1")
     return dw
+
+
+# ---------------------------------------------------------------- f4: supervised CutPaste / mirror pre-training
+CUTPASTE_PARAMS = 20      # CP2_CUTPASTE_PARAMS
+MIRROR_MAX_CLASSES = 8    # CP2_MIRROR_MAX_CLASSES
+
+
+def cutpaste(src: torch.Tensor, src_mirror: Optional[torch.Tensor], params: torch.Tensor, mask: Optional[torch.Tensor] = None,
+             want_u8: bool = False, want_f32: bool = True):
+    """One patch round of CutPasteDataset.cutpaste for a batch (reference datasets/pretrain_dataset.py:273-352).
+    src / src_mirror: uint8 [*,H,W,3] on the GPU (src_mirror None = MirrorVariant.NONE); params: int32 [B,20] device
+    table (mirror.cutpaste_table); mask: None (first round: written) or the int64 [B,H,W] mask of the previous round
+    (updated in place with logical_or).  Returns dict(u8, mirror_u8, f32, mirror_f32, mask)."""
+    lib = _lib.load()
+    if not src.is_cuda or src.dtype != torch.uint8 or src.dim() != 4 or src.shape[3] != 3:
+        raise _lib.Cp2LibraryError("cutpaste: src must be a uint8 [*,H,W,3] GPU tensor")
+    _, H, W, _ = src.shape
+    if src_mirror is not None and (src_mirror.dtype != torch.uint8 or tuple(src_mirror.shape[1:]) != (H, W, 3)):
+        raise ValueError("cutpaste: src_mirror must be uint8 [*,H,W,3] of the same image size")
+    if params.dim() != 2 or params.shape[1] != CUTPASTE_PARAMS:
+        raise ValueError(f"cutpaste: params must be int32 [B,{CUTPASTE_PARAMS}]")
+    B = params.shape[0]
+    dev = src.device
+    mask_or = mask is not None
+    if mask is None:
+        mask = torch.empty((B, H, W), dtype=torch.int64, device=dev)
+    elif tuple(mask.shape) != (B, H, W):
+        raise ValueError("cutpaste: mask must be int64 [B,H,W]")
+    mir = src_mirror is not None
+    u8 = torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev) if want_u8 else None
+    mu8 = torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev) if want_u8 and mir else None
+    f32 = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev) if want_f32 else None
+    mf32 = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev) if want_f32 and mir else None
+    rc = lib.cp2_cutpaste(_dev(src, "src"), _opt(src_mirror, "src_mirror"), _dev(params, "params", torch.int32), _opt(u8, "u8"),
+                          _opt(mu8, "mu8"), _opt(f32, "f32"), _opt(mf32, "mf32"), _dev(mask, "mask", torch.int64),
+                          int(mask_or), B, H, W, _stream())
+    _lib.check(rc, "cp2_cutpaste")
+    return dict(u8=u8, mirror_u8=mu8, f32=f32, mirror_f32=mf32, mask=mask)
+
+
+def mirror_loss(s_logits: torch.Tensor, t_logits: Optional[torch.Tensor], masks: torch.Tensor, softmax_temp: float,
+                lmbd_compare_loss: float, want_grad: bool = True, want_argmax: bool = True,
+                confusion: Optional[torch.Tensor] = None):
+    """MirrorModule.shared_step's loss section in one pass (reference networks/mirror_network.py:40-63).
+    s_logits / t_logits: float32 [N,C,H,W] at image size (t_logits None = MirrorVariant.NONE); masks int64 [N,H,W].
+    Returns (out3 = [loss, class_loss, compare_loss], grad_s, grad_t, argmax [(2)N,H,W]); confusion (int64 [C,C],
+    row = ground truth) is added to in place when given."""
+    lib = _lib.load()
+    N, C, H, W = s_logits.shape
+    HW = H * W
+    dev = s_logits.device
+    if t_logits is not None and t_logits.shape != s_logits.shape:
+        raise ValueError("mirror_loss: s_logits and t_logits must have the same shape")
+    if tuple(masks.shape) != (N, H, W):
+        raise ValueError(f"mirror_loss: masks must be [N,H,W] = {(N, H, W)}, got {tuple(masks.shape)}")
+    if confusion is not None and tuple(confusion.shape) != (C, C):
+        raise ValueError("mirror_loss: confusion must be int64 [C,C]")
+    two = t_logits is not None
+    gs = torch.empty_like(s_logits) if want_grad else None
+    gt = torch.empty_like(s_logits) if want_grad and two else None
+    am = torch.empty(((2 if two else 1) * N, H, W), dtype=torch.int64, device=dev) if want_argmax else None
+    nparts = lib.cp2_mirror_loss_num_partials(N, HW)
+    part = torch.empty(2 * nparts, dtype=torch.float64, device=dev)
+    out3 = torch.empty(3, dtype=torch.float32, device=dev)
+    _profile("mirror_loss")
+    rc = lib.cp2_mirror_loss(_dev(s_logits, "s_logits", torch.float32), _opt(t_logits, "t_logits", torch.float32),
+                             _dev(masks, "masks", torch.int64), float(softmax_temp), float(lmbd_compare_loss), _opt(gs, "gs"),
+                             _opt(gt, "gt"), _opt(am, "argmax"), _opt(confusion, "confusion", torch.int64), part.data_ptr(),
+                             out3.data_ptr(), N, C, HW, _stream())
+    _lib.check(rc, "cp2_mirror_loss")
+    return out3, gs, gt, am

@@ -255,6 +255,38 @@ int cp2_bn_bwd(const void* x, const void* dy, const void* y, const float* weight
 int cp2_wgrad1x1_num_splits(int M, int CO, int CI);
 int cp2_wgrad1x1(const void* dy, const void* x, float* dw, float* part, int M, int CO, int CI, void* stream);
 
+/* ---- supervised CutPaste / "mirror" pre-training ------------------------------------------------
+ * cp2_cutpaste replaces the per-sample numpy / Pillow composition of datasets/pretrain_dataset.py:273-352 (cutpaste)
+ * and :357-412 (__getitem__: additional patches, ToTensor).  One launch = one patch round for a whole batch:
+ *   src / src_mirror: uint8 [*, H, W, 3] device arrays (the resident dataset in round 1, the previous round's dst /
+ *   dst_mirror afterwards; src_mirror NULL = MirrorVariant.NONE); params: device int32 [B, CP2_CUTPASTE_PARAMS] =
+ *   {src index, mirror index, class (0 = copy the sample through), patch x, patch y, patch w, patch h, paste x,
+ *    paste y, rotated w, rotated h, a0..a5 (Pillow's 16.16 fixed-point reverse matrix: source pixel of rotated-patch
+ *    pixel (u, v) = ((a2 + u*a0 + v*a1) >> 16, (a5 + u*a3 + v*a4) >> 16); pixels that fall outside the patch are not
+ *    pasted), 0, 0, 0};
+ *   dst / dst_mirror: uint8 [B, H, W, 3] or NULL; dst_f32 / dst_mirror_f32: float [B, 3, H, W] = ToTensor (u8 / 255)
+ *   or NULL; mask: int64 [B, H, W], written with class inside the pasted shape and 0 elsewhere, or, with mask_or != 0,
+ *   logical_or(old mask, pasted shape) as 0 / 1 (class-0 samples keep their old mask).  dst must not alias src. */
+#define CP2_CUTPASTE_PARAMS 20
+int cp2_cutpaste(const unsigned char* src, const unsigned char* src_mirror, const int32_t* params, unsigned char* dst,
+                 unsigned char* dst_mirror, float* dst_f32, float* dst_mirror_f32, int64_t* mask, int mask_or, int B,
+                 int H, int W, void* stream);
+/* cp2_mirror_loss replaces networks/mirror_network.py:40-63 (MirrorModule.shared_step) after the resize of
+ * networks/segment_network.py:220-231:  class_loss = cross_entropy(cat(s, t), cat(masks, masks)) (mean over all
+ * pixels), compare_loss = cross_entropy(softmax(s / T, 1), softmax(t / T, 1)) with probability targets (mean over
+ * N*HW), loss = class_loss + lmbd * compare_loss.  s_logits, t_logits: float [N, C, HW] (t_logits NULL =
+ * MirrorVariant.NONE: class loss of s alone, compare_loss = 0); masks: int64 [N, HW] in [0, C); 2 <= C <=
+ * CP2_MIRROR_MAX_CLASSES.  Outputs: out3 float[3] = {loss, class_loss, compare_loss}; grad_s / grad_t: d loss / d
+ * logits (NULL = forward only; both or neither when t_logits is given -- the compare loss differentiates through its
+ * target as autograd does); argmax: int64 [(t ? 2 : 1) * N, HW] or NULL; confusion: int64 [C, C] (row = ground truth,
+ * column = prediction), ADDED to -- the caller zeroes it -- or NULL.  Workspace: partial double[2 *
+ * cp2_mirror_loss_num_partials(N, HW)]; the partial sums are added in a fixed order (deterministic). */
+#define CP2_MIRROR_MAX_CLASSES 8
+int cp2_mirror_loss_num_partials(int N, int64_t HW);
+int cp2_mirror_loss(const float* s_logits, const float* t_logits, const int64_t* masks, float softmax_temp,
+                    float lmbd_compare_loss, float* grad_s, float* grad_t, int64_t* argmax, int64_t* confusion,
+                    double* partial, float* out3, int N, int C, int64_t HW, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
