@@ -48,15 +48,16 @@ SIGNATURES = {
     "cp2_bn_num_partials": [c_int, c_int],
     "cp2_bn_fwd": [_P, _P, _P, _P, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P],
     "cp2_bn_bwd": [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, _P],
-    "cp2_masked_quantiles": [_P, c_int64, c_int64, c_int, c_int, _P, _P, c_int, c_int, _P, c_int, _P, _P],
-    "cp2_masked_quantiles_multi": [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P],
+    "cp2_masked_quantiles": [_P, c_int64, c_int64, c_int, c_int, _P, _P, c_int, c_int, _P, c_int, _P, _P, c_int64, _P],
+    "cp2_quantiles_workspace_bytes": [c_int, _P, _P, c_int],
+    "cp2_masked_quantiles_multi": [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, c_int64, _P],
     "cp2_cutpaste": [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "cp2_mirror_loss_num_partials": [c_int, c_int64],
     "cp2_mirror_loss": [_P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int64, _P],
     "cp2_dense_infonce_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, _P, _P, c_float,
                               _P, _P, c_int, c_float, _P, c_int, c_int, c_int, _P],
 }
-_RESTYPE = {"cp2_error_string": c_char_p}
+_RESTYPE = {"cp2_error_string": c_char_p, "cp2_quantiles_workspace_bytes": c_int64}
 
 _lib = None
 

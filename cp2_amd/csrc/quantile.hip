@@ -2,13 +2,28 @@
 //   tools/correlation_mapping.py:16-53  per-sample nanquantile([.25,.5,.75]) of the positive / negative dense
 //                                       scores (pairs selected by mask_a[x]*mask_b[y])
 //   builder.py:1399-1406                row quantiles of the b x K queue logits
-// Exact order statistics without sorting: ONE workgroup per row finds all requested quantiles together by a
-// three-pass radix select (12 + 10 + 10 bits of the order-preserving integer image of the floats, LDS histograms),
-// then interpolates exactly as torch.quantile(..., interpolation='linear') does:
-//   rank = q*(n-1) in fp32, lerp(v_lo, v_hi, frac).
-// The interpolation partner (the next larger element) comes out of the last pass for free: it is the same key again
-// (multiplicity), the next non-empty bin of the last histogram, or the smallest key above the 22-bit prefix, which
-// that pass tracks with a running minimum.  (Round 1 ran one workgroup per (row, quantile) and six passes each.)
+// Exact order statistics without sorting: a radix select over the order-preserving integer image of the floats
+// (12 + 10 + 10 bits), all requested quantiles of a row together, then the interpolation of
+// torch.quantile(..., interpolation='linear'):  rank = q*(n-1) in fp32, lerp(v_lo, v_hi, frac).
+//
+// Round 1 / early round 2 ran ONE workgroup per row through three passes over the row: 96 workgroups on 256 CUs, each
+// VALU-bound on its CU (66 us per step at 32 x 65536 + 2 x 32 x 196^2; at BASELINE config 4, 16 rows of 16.7 M
+// elements, it would leave the chip idle).  Now every row is cut into 8192-element chunks and the work is three launches:
+//   K1  quantile_hist_kernel     one workgroup per chunk: LDS histogram of the top 12 bits, non-zero bins added to the
+//                                row's global histogram
+//   K2  quantile_compact_kernel  one workgroup per chunk: finds the row's bin of every quantile from that histogram
+//                                (every workgroup of the row, redundantly), appends its chunk's elements of those bins
+//                                to the row's candidate lists (staged in LDS, ONE returning atomic per workgroup and
+//                                quantile), adds their next 10 bits to the row's second-level histograms and tracks the
+//                                smallest key above each bin (the interpolation partner when a bin's maximum is selected)
+//   K3  quantile_final_kernel    one workgroup per row: second- and third-level select over the candidates only (about
+//                                1.5 % of a row for Gaussian-like logits; the whole row again if a list overflowed),
+//                                interpolation, and the row's workspace is left zeroed for the next call
+// Integer counting only: the result does not depend on the order in which atomics arrive (bit-exact vs torch.nanquantile).
+// The logits are read from memory, i.e. they ARE materialised by the loss kernels when quartile logging is on: building
+// the first histogram inside the loss kernels would need 32 rows x 4096 bins of LDS per tile (512 KB), and recomputing
+// the P x P logits in K1 and K2 costs two more MFMA passes (2 x 0.44 ms at config 4) against 0.27 ms for writing them
+// once and reading them twice at HBM speed.
 #include "common.hpp"
 #include <math.h>
 
@@ -18,6 +33,9 @@ struct QuantArgs {
     const float* q; int NQ;
     float* out;                                            // [NQ][R] (torch.quantile layout)
     int R;
+    int chunks;                                            // ceil(N / QCHUNK)
+    int cap;                                               // candidate slots per (row, quantile)
+    int64_t cand_off;                                      // offset (in words) of this job's candidate lists in the workspace
 };
 
 __device__ __forceinline__ unsigned f2key(float f) {
@@ -28,11 +46,31 @@ __device__ __forceinline__ float key2f(unsigned k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
-constexpr int QT = 1024;      // threads per workgroup
-constexpr int QMAX = 4;       // quantiles per call
-constexpr int QB0 = 4096, QB1 = 1024;
+constexpr int QMAX = 4;                   // quantiles per call
+constexpr int QB0 = 4096, QB1 = 1024;     // bins of the first / second and third level
+constexpr int QCHUNK = 8192;              // elements per workgroup in K1 / K2
+constexpr int QT1 = 256;                  // threads per workgroup in K1 / K2
+constexpr int QT3 = 1024;                 // threads per workgroup in K3
+constexpr int QSTAGE = 1024;              // candidates one chunk may stage per quantile before the row falls back
+constexpr int QJOBS = 4;
+constexpr unsigned QNONE = 0xFFFFFFFFu;
 
-// inclusive prefix sum of one unsigned per thread over the 1024 threads of the workgroup (wtot: 16 words of LDS)
+struct QuantJobs {
+    QuantArgs job[QJOBS];
+    int first_row[QJOBS + 1];              // rows of job j: [first_row[j], first_row[j+1])
+    int first_chunk[QJOBS + 1];            // chunk workgroups of job j
+    // workspace (device, zero between calls): per global row rt
+    unsigned* hist0;                       // [rows][QB0]
+    unsigned* hist1;                       // [rows][QMAX][QB1]
+    unsigned* ccount;                      // [rows][QMAX] candidates appended
+    unsigned* above;                       // [rows][QMAX] max over ~key of the elements above the bin (0 = none)
+    unsigned* cand;                        // per job: [R][NQ][cap] keys
+};
+
+// per-row workspace header words: hist0 | hist1 | ccount | above
+constexpr int64_t QROW_WORDS = QB0 + QMAX * QB1 + 2 * QMAX;
+
+template <int NT>
 __device__ __forceinline__ unsigned block_scan_incl(unsigned v, unsigned* wtot) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     unsigned incl = v;
@@ -49,172 +87,405 @@ __device__ __forceinline__ unsigned block_scan_incl(unsigned v, unsigned* wtot) 
     return incl + base;
 }
 
-// Up to QJOBS independent problems in ONE launch (the three logging statistics of a CP2 step: queue-logit rows,
-// positive and negative dense pairs): a workgroup handles one row of one job, so 96 CUs work for one launch duration
-// instead of 32 CUs three times in a row.
-constexpr int QJOBS = 4;
-struct QuantJobs {
-    QuantArgs job[QJOBS];
-    int first_row[QJOBS + 1];                              // workgroup b belongs to job j with first_row[j] <= b < first_row[j+1]
-};
-
-__global__ __launch_bounds__(QT) void quantiles_kernel(QuantJobs jobs) {
-    int jsel = 0;
-#pragma unroll
-    for (int j = 1; j < QJOBS; ++j) jsel += ((int)blockIdx.x >= jobs.first_row[j]) ? 1 : 0;
-    const QuantArgs& a = jobs.job[jsel];
-    extern __shared__ __attribute__((aligned(16))) unsigned char q_smem[];
-    __shared__ unsigned hist0[QB0];
-    __shared__ unsigned hist[QMAX][QB1];
-    __shared__ unsigned wtot[16];
-    __shared__ unsigned sh_prefix[QMAX], sh_k[QMAX], sh_min[QMAX], sh_next[QMAX], sh_n;
-    float* lma = reinterpret_cast<float*>(q_smem);
-    float* lmb = lma + (a.want >= 0 ? a.P : 0);
-    const int r = (int)blockIdx.x - jobs.first_row[jsel], tid = threadIdx.x, NQ = a.NQ;
+// Visit the kept elements i in [begin, end) of row r (begin % 4 == 0): f(key).  16-byte loads when the row is contiguous.
+template <int NT, typename F>
+__device__ __forceinline__ void for_each_kept(const QuantArgs& a, int r, int begin, int end, F&& f) {
     const float* row = a.x + (int64_t)r * a.s_row;
     const bool masked = a.want >= 0;
-    if (masked) {
-        for (int i = tid; i < a.P; i += QT) { lma[i] = a.mask_a[(int64_t)r * a.P + i]; lmb[i] = a.mask_b[(int64_t)r * a.P + i]; }
-    }
-    for (int i = tid; i < QB0; i += QT) hist0[i] = 0;
-    __syncthreads();
+    const float* ma = masked ? a.mask_a + (int64_t)r * a.P : nullptr;
+    const float* mb = masked ? a.mask_b + (int64_t)r * a.P : nullptr;
+    const bool wantpos = a.want != 0;
+    const int tid = threadIdx.x;
     const bool vec = a.s_elem == 1 && ((reinterpret_cast<uintptr_t>(row) & 15u) == 0);
-    auto keep_at = [&](int x, int y, float v) -> bool {
-        if (v != v) return false;                          // nanquantile ignores NaN
-        if (!masked) return true;
-        return ((lma[x] * lmb[y]) != 0.f) == (a.want != 0);
-    };
-    // Visit every kept element of the row once: 16-byte loads when the row is contiguous, four loads in flight otherwise.
-#define CP2_Q_FOREACH(BODY)                                                                              \
-    if (vec) {                                                                                           \
-        const int n4 = (a.N + 3) >> 2;                                                                   \
-        for (int j4 = tid; j4 < n4; j4 += 4 * QT) {                                                      \
-            float4 t4[4];                                                                                \
-            _Pragma("unroll") for (int g = 0; g < 4; ++g) {      /* four 16-byte loads in flight */       \
-                const int i0 = (j4 + g * QT) * 4;                                                        \
-                if (i0 + 3 < a.N) {                                                                      \
-                    t4[g] = *reinterpret_cast<const float4*>(row + i0);                                  \
-                } else {                                                                                 \
-                    t4[g].x = (i0 + 0 < a.N) ? row[i0 + 0] : NAN;                                        \
-                    t4[g].y = (i0 + 1 < a.N) ? row[i0 + 1] : NAN;                                        \
-                    t4[g].z = (i0 + 2 < a.N) ? row[i0 + 2] : NAN;                                        \
-                    t4[g].w = NAN;                                                                       \
-                }                                                                                        \
-            }                                                                                            \
-            _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                              \
-                const int i0 = (j4 + g * QT) * 4;                                                        \
-                const float vv[4] = {t4[g].x, t4[g].y, t4[g].z, t4[g].w};                                \
-                int x_ = masked ? i0 / a.P : 0, y_ = masked ? i0 % a.P : 0;                              \
-                _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                          \
-                    const float v = vv[u];                                                               \
-                    if (keep_at(x_, y_, v)) { BODY }                                                     \
-                    if (masked && ++y_ >= a.P) { y_ = 0; ++x_; }                                         \
-                }                                                                                        \
-            }                                                                                            \
-        }                                                                                                \
-    } else {                                                                                             \
-        for (int i0 = tid; i0 < a.N; i0 += 4 * QT) {                                                     \
-            float vv[4];                                                                                 \
-            _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                              \
-                const int i = i0 + u * QT;                                                               \
-                vv[u] = i < a.N ? row[(int64_t)i * a.s_elem] : NAN;                                      \
-            }                                                                                            \
-            _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                              \
-                const int i = i0 + u * QT;                                                               \
-                const float v = vv[u];                                                                   \
-                if (keep_at(masked ? i / a.P : 0, masked ? i % a.P : 0, v)) { BODY }                     \
-            }                                                                                            \
-        }                                                                                                \
+    if (vec) {
+        for (int i0 = begin + tid * 4; i0 < end; i0 += NT * 4 * 2) {
+            float4 t4[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {                  // two 16-byte loads in flight
+                const int i = i0 + g * NT * 4;
+                if (i + 3 < end) {
+                    t4[g] = *reinterpret_cast<const float4*>(row + i);
+                } else {
+                    t4[g].x = (i + 0 < end) ? row[i + 0] : NAN;
+                    t4[g].y = (i + 1 < end) ? row[i + 1] : NAN;
+                    t4[g].z = (i + 2 < end) ? row[i + 2] : NAN;
+                    t4[g].w = NAN;
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int i = i0 + g * NT * 4;
+                if (i >= end) break;
+                const float vv[4] = {t4[g].x, t4[g].y, t4[g].z, t4[g].w};
+                int x_ = 0, y_ = 0;
+                float fa = 0.f;
+                if (masked) { x_ = i / a.P; y_ = i - x_ * a.P; fa = ma[x_]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float v = vv[u];
+                    bool keep = v == v;                    // nanquantile ignores NaN (also the padding above)
+                    if (masked && keep) keep = ((fa * mb[y_]) != 0.f) == wantpos;
+                    if (keep) f(f2key(v));
+                    if (masked && ++y_ >= a.P) { y_ = 0; ++x_; fa = (x_ < a.P) ? ma[x_] : 0.f; }
+                }
+            }
+        }
+    } else {
+        for (int i = begin + tid; i < end; i += NT) {
+            const float v = row[(int64_t)i * a.s_elem];
+            bool keep = v == v;
+            if (masked && keep) { const int x_ = i / a.P; keep = ((ma[x_] * mb[i - x_ * a.P]) != 0.f) == wantpos; }
+            if (keep) f(f2key(v));
+        }
     }
+}
 
-    // ---- pass 0: top 12 bits, one histogram for all quantiles (its total is n)
-    CP2_Q_FOREACH(atomicAdd(&hist0[f2key(v) >> 20], 1u);)
+// One chunk (QCHUNK elements = 8 float4 per thread of a 256-thread workgroup), split into "issue every load" and
+// "process": K1 / K2 put all global loads of a workgroup (data and histograms) in flight at once, so a workgroup pays ONE
+// memory round trip instead of one per loop iteration.
+template <int NT>
+struct ChunkData {
+    static constexpr int G = QCHUNK / (NT * 4);
+    float4 v[G];
+    bool vec;
+};
+
+template <int NT>
+__device__ __forceinline__ void chunk_load(const QuantArgs& a, int r, int begin, int end, ChunkData<NT>& d) {
+    const float* row = a.x + (int64_t)r * a.s_row;
+    d.vec = a.s_elem == 1 && ((reinterpret_cast<uintptr_t>(row) & 15u) == 0);
+    if (!d.vec) return;
+#pragma unroll
+    for (int g = 0; g < ChunkData<NT>::G; ++g) {
+        const int i = begin + (g * NT + (int)threadIdx.x) * 4;
+        if (i + 3 < end) {
+            d.v[g] = *reinterpret_cast<const float4*>(row + i);
+        } else {
+            d.v[g].x = (i + 0 < end) ? row[i + 0] : NAN;
+            d.v[g].y = (i + 1 < end) ? row[i + 1] : NAN;
+            d.v[g].z = (i + 2 < end) ? row[i + 2] : NAN;
+            d.v[g].w = NAN;
+        }
+    }
+}
+
+template <int NT, typename F>
+__device__ __forceinline__ void chunk_visit(const QuantArgs& a, int r, int begin, int end, const ChunkData<NT>& d, F&& f) {
+    if (!d.vec) { for_each_kept<NT>(a, r, begin, end, f); return; }
+    const bool masked = a.want >= 0;
+    const float* ma = masked ? a.mask_a + (int64_t)r * a.P : nullptr;
+    const float* mb = masked ? a.mask_b + (int64_t)r * a.P : nullptr;
+    const bool wantpos = a.want != 0;
+    int x0 = 0, rem0 = 0;
+    float invP = 0.f;
+    bool mvec = false;
+    if (masked) {
+        x0 = begin / a.P; rem0 = begin - x0 * a.P; invP = 1.0f / (float)a.P;       // uniform: scalar unit
+        mvec = (a.P & 3) == 0 && ((reinterpret_cast<uintptr_t>(mb) & 15u) == 0);
+    }
+#pragma unroll
+    for (int g = 0; g < ChunkData<NT>::G; ++g) {
+        const int loc = (g * NT + (int)threadIdx.x) * 4, i = begin + loc;
+        if (i >= end) break;
+        const float vv[4] = {d.v[g].x, d.v[g].y, d.v[g].z, d.v[g].w};
+        if (!masked) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (vv[u] == vv[u]) f(f2key(vv[u]));
+            continue;
+        }
+        // (x, y) of element i: rem0 + loc < P + QCHUNK, exact through a float quotient and one correction
+        const int t = rem0 + loc;
+        int dx = (int)((float)t * invP);
+        if (dx * a.P > t) --dx; else if ((dx + 1) * a.P <= t) ++dx;
+        int x_ = x0 + dx, y_ = t - dx * a.P;
+        if (mvec) {                                        // P % 4 == 0: the four elements share x, mask_b as one load
+            const float fa = x_ < a.P ? ma[x_] : 0.f;
+            const float4 m4 = x_ < a.P ? *reinterpret_cast<const float4*>(mb + y_) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float mm[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float v = vv[u];
+                if (v == v && (((fa * mm[u]) != 0.f) == wantpos)) f(f2key(v));
+            }
+        } else {
+            float fa = x_ < a.P ? ma[x_] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float v = vv[u];
+                bool keep = v == v;
+                if (keep) keep = ((fa * mb[y_]) != 0.f) == wantpos;
+                if (keep) f(f2key(v));
+                if (++y_ >= a.P) { y_ = 0; ++x_; fa = (x_ < a.P) ? ma[x_] : 0.f; }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ int job_of(const int* first, int b) {
+    int jsel = 0;
+#pragma unroll
+    for (int j = 1; j < QJOBS; ++j) jsel += (b >= first[j]) ? 1 : 0;
+    return jsel;
+}
+
+// The thread that holds rank `lo` among its BPT consecutive bins (exclusive / inclusive prefix of its bins' total:
+// excl, incl) publishes the bin and the rank inside it.
+template <int BPT>
+__device__ __forceinline__ void locate(const unsigned (&hv)[BPT], unsigned excl, unsigned incl, unsigned lo, unsigned* bin,
+                                       unsigned* kk) {
+    if (lo >= excl && lo < incl) {
+        unsigned k = lo - excl;
+        int b = 0;
+#pragma unroll
+        for (int u = 0; u < BPT - 1; ++u)
+            if (b == u && k >= hv[u]) { k -= hv[u]; ++b; }
+        *bin = (unsigned)(BPT * (int)threadIdx.x + b);
+        *kk = k;
+    }
+}
+
+// ---- K1: first-level histogram of one chunk -> the row's global histogram
+__global__ __launch_bounds__(QT1) void quantile_hist_kernel(QuantJobs jobs) {
+    __shared__ unsigned h[QB0];
+    const int jsel = job_of(jobs.first_chunk, (int)blockIdx.x);
+    const QuantArgs& a = jobs.job[jsel];
+    const int c = (int)blockIdx.x - jobs.first_chunk[jsel], r = c / a.chunks, s = c - r * a.chunks;
+    const int tid = threadIdx.x;
+    const int begin = s * QCHUNK, end = min(a.N, begin + QCHUNK);
+    ChunkData<QT1> d;
+    chunk_load<QT1>(a, r, begin, end, d);                  // every load of the workgroup in flight
+    for (int i = tid; i < QB0; i += QT1) h[i] = 0;
     __syncthreads();
+    chunk_visit<QT1>(a, r, begin, end, d, [&](unsigned k) { atomicAdd(&h[k >> 20], 1u); });
+    __syncthreads();
+    unsigned* g = jobs.hist0 + (int64_t)(jobs.first_row[jsel] + r) * QB0;
+    for (int i = tid; i < QB0; i += QT1) {
+        const unsigned v = h[i];
+        if (v) atomicAdd(&g[i], v);
+    }
+}
+
+// ---- K2: candidates of one chunk
+__global__ __launch_bounds__(QT1) void quantile_compact_kernel(QuantJobs jobs) {
+    __shared__ unsigned h1[QMAX][QB1];
+    __shared__ unsigned stage[QMAX][QSTAGE];
+    __shared__ unsigned wtot[QT1 / 64];
+    __shared__ unsigned sh_bin[QMAX], sh_kk[QMAX], sh_cnt[QMAX], sh_min[QMAX], sh_base[QMAX], sh_n;
+    const int jsel = job_of(jobs.first_chunk, (int)blockIdx.x);
+    const QuantArgs& a = jobs.job[jsel];
+    const int c = (int)blockIdx.x - jobs.first_chunk[jsel], r = c / a.chunks, s = c - r * a.chunks;
+    const int tid = threadIdx.x, NQ = a.NQ;
+    const int64_t rt = jobs.first_row[jsel] + r;
+    const int begin = s * QCHUNK, end = min(a.N, begin + QCHUNK);
+    // one memory round trip: the row's first-level histogram (16 bins per thread) and this chunk's data
+    constexpr int BPT = QB0 / QT1;
+    unsigned hv[BPT];
     {
-        const unsigned h0 = hist0[4 * tid], h1 = hist0[4 * tid + 1], h2 = hist0[4 * tid + 2], h3 = hist0[4 * tid + 3];
-        const unsigned tot = h0 + h1 + h2 + h3;
-        const unsigned incl = block_scan_incl(tot, wtot), excl = incl - tot;
-        if (tid == QT - 1) sh_n = incl;
-        __syncthreads();
-        const unsigned n = sh_n;
-        if (n == 0) {
-            if (tid < NQ) a.out[(int64_t)tid * a.R + r] = NAN;
-            return;
-        }
-        for (int j = 0; j < NQ; ++j) {
-            const unsigned lo = (unsigned)floorf(a.q[j] * (float)(n - 1));
-            if (lo >= excl && lo < incl) {
-                unsigned kk = lo - excl, b = 4 * tid;
-                if (kk >= h0) { kk -= h0; ++b; if (kk >= h1) { kk -= h1; ++b; if (kk >= h2) { kk -= h2; ++b; } } }
-                sh_prefix[j] = b;
-                sh_k[j] = kk;
-            }
+        const uint4* g4 = reinterpret_cast<const uint4*>(jobs.hist0 + rt * QB0 + BPT * tid);
+#pragma unroll
+        for (int u = 0; u < BPT / 4; ++u) {
+            const uint4 t = g4[u];
+            hv[4 * u] = t.x; hv[4 * u + 1] = t.y; hv[4 * u + 2] = t.z; hv[4 * u + 3] = t.w;
         }
     }
-    // ---- passes 1 and 2: ten more bits each, one histogram per quantile
-    for (int pass = 1; pass <= 2; ++pass) {
-        for (int i = tid; i < QMAX * QB1; i += QT) (&hist[0][0])[i] = 0;
-        if (tid < QMAX) { sh_min[tid] = 0xFFFFFFFFu; sh_next[tid] = 0xFFFFFFFFu; }
-        __syncthreads();
-        unsigned pre[QMAX], mn[QMAX];
+    ChunkData<QT1> d;
+    chunk_load<QT1>(a, r, begin, end, d);
+    if (tid < QMAX) { sh_cnt[tid] = 0; sh_min[tid] = QNONE; sh_bin[tid] = QNONE; }
+    for (int i = tid; i < QMAX * QB1; i += QT1) (&h1[0][0])[i] = 0;
+    unsigned tot = 0;
 #pragma unroll
-        for (int j = 0; j < QMAX; ++j) { pre[j] = j < NQ ? sh_prefix[j] : 0xFFFFFFFFu; mn[j] = 0xFFFFFFFFu; }
-        const int sh = pass == 1 ? 20 : 10;
-        CP2_Q_FOREACH(
-            const unsigned k = f2key(v);
-            const unsigned top = k >> sh;
-            const unsigned bin = (k >> (sh - 10)) & (QB1 - 1);
-            _Pragma("unroll") for (int j = 0; j < QMAX; ++j) {
-                if (top == pre[j]) atomicAdd(&hist[j][bin], 1u);
-                else if (pass == 2 && j < NQ && top > pre[j]) mn[j] = min(mn[j], k);
-            })
-        if (pass == 2) {
+    for (int u = 0; u < BPT; ++u) tot += hv[u];
+    const unsigned incl = block_scan_incl<QT1>(tot, wtot), excl = incl - tot;
+    if (tid == QT1 - 1) sh_n = incl;
+    __syncthreads();
+    const unsigned n = sh_n;
+    if (n == 0) return;                                    // nothing kept in this row: K3 writes NaN
+    for (int j = 0; j < NQ; ++j)
+        locate<BPT>(hv, excl, incl, (unsigned)floorf(a.q[j] * (float)(n - 1)), &sh_bin[j], &sh_kk[j]);
+    __syncthreads();
+    unsigned bin[QMAX], mn[QMAX];
 #pragma unroll
-            for (int j = 0; j < QMAX; ++j) {
-                unsigned m = mn[j];
+    for (int j = 0; j < QMAX; ++j) { bin[j] = j < NQ ? sh_bin[j] : QNONE; mn[j] = QNONE; }
+    chunk_visit<QT1>(a, r, begin, end, d, [&](unsigned k) {
+        const unsigned top = k >> 20;
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, off, 64));
-                if ((tid & 63) == 0 && m != 0xFFFFFFFFu) atomicMin(&sh_min[j], m);
+        for (int j = 0; j < QMAX; ++j) {
+            if (top == bin[j]) {
+                const unsigned slot = atomicAdd(&sh_cnt[j], 1u);
+                if (slot < QSTAGE) stage[j][slot] = k;
+                atomicAdd(&h1[j][(k >> 10) & (QB1 - 1)], 1u);
+            } else if (j < NQ && top > bin[j]) {
+                mn[j] = min(mn[j], k);
             }
         }
-        __syncthreads();
-        for (int j = 0; j < NQ; ++j) {
-            const unsigned hv = hist[j][tid];
-            const unsigned incl = block_scan_incl(hv, wtot), excl = incl - hv;
-            const unsigned kk0 = sh_k[j];
-            __syncthreads();                               // everyone has read sh_k[j] before it is rewritten
-            if (kk0 >= excl && kk0 < incl) {
-                sh_prefix[j] = (pre[j] << 10) | (unsigned)tid;
-                sh_k[j] = kk0 - excl;
-            }
-            __syncthreads();
-            if (pass == 2) {
-                // the next non-empty bin above the selected one (the partner when the selected key is not repeated)
-                const unsigned sel = sh_prefix[j] & (QB1 - 1);
-                if (hv != 0 && (unsigned)tid > sel) atomicMin(&sh_next[j], (unsigned)tid);
-            }
-        }
-        __syncthreads();
+    });
+#pragma unroll
+    for (int j = 0; j < QMAX; ++j) {
+        unsigned m = mn[j];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, off, 64));
+        if ((tid & 63) == 0 && m != QNONE) atomicMin(&sh_min[j], m);
     }
+    __syncthreads();
+    unsigned* ccount = jobs.ccount + rt * QMAX;
+    if (tid < NQ) {
+        const unsigned cnt = sh_cnt[tid];
+        // a chunk with more matches than it can stage marks the row's count: K3 then re-reads the row itself
+        unsigned base = 0;
+        if (cnt > QSTAGE) atomicOr(&ccount[tid], 0x80000000u);
+        else if (cnt) base = atomicAdd(&ccount[tid], cnt);
+        sh_base[tid] = base;
+        if (sh_min[tid] != QNONE) atomicMax(&jobs.above[rt * QMAX + tid], ~sh_min[tid]);
+    }
+    unsigned* g1 = jobs.hist1 + rt * QMAX * QB1;
+    for (int j = 0; j < NQ; ++j)
+        for (int i = tid; i < QB1; i += QT1) {
+            const unsigned v = h1[j][i];
+            if (v) atomicAdd(&g1[j * QB1 + i], v);
+        }
+    __syncthreads();
+    for (int j = 0; j < NQ; ++j) {
+        const unsigned cnt = sh_cnt[j], base = sh_base[j];
+        if (cnt <= QSTAGE) {
+            unsigned* dst = jobs.cand + a.cand_off + ((int64_t)r * NQ + j) * a.cap;
+            for (unsigned i = tid; i < cnt; i += QT1)
+                if (base + i < (unsigned)a.cap) dst[base + i] = stage[j][i];
+        }
+    }
+}
+
+// ---- K3: one workgroup per row: levels two and three over the candidates, interpolation, workspace clean-up
+__global__ __launch_bounds__(QT3) void quantile_final_kernel(QuantJobs jobs) {
+    __shared__ unsigned h2[QMAX][QB1];
+    __shared__ unsigned wtot[QT3 / 64];
+    __shared__ unsigned sh_bin0[QMAX], sh_kk[QMAX], sh_bin1[QMAX], sh_bin2[QMAX], sh_min[QMAX], sh_next[QMAX], sh_n;
+    const int jsel = job_of(jobs.first_row, (int)blockIdx.x);
+    const QuantArgs& a = jobs.job[jsel];
+    const int r = (int)blockIdx.x - jobs.first_row[jsel], tid = threadIdx.x, NQ = a.NQ;
+    const int64_t rt = blockIdx.x;
+    unsigned* g0 = jobs.hist0 + rt * QB0;
+    unsigned* g1 = jobs.hist1 + rt * QMAX * QB1;
+    unsigned* ccount = jobs.ccount + rt * QMAX;
+    unsigned* above = jobs.above + rt * QMAX;
+    // one memory round trip: both histogram levels, the candidate counts and the first candidate of every thread
+    constexpr int BPT = QB0 / QT3;
+    static_assert(BPT == 4 && QB1 == QT3, "one uint4 of first-level bins and one second-level bin per thread");
+    unsigned hv[BPT], h1v[QMAX], cnt[QMAX], c0[QMAX];
+    {
+        const uint4 t = reinterpret_cast<const uint4*>(g0)[tid];
+        hv[0] = t.x; hv[1] = t.y; hv[2] = t.z; hv[3] = t.w;
+    }
+    bool overflow = false;
+#pragma unroll
+    for (int j = 0; j < QMAX; ++j) {
+        h1v[j] = j < NQ ? g1[j * QB1 + tid] : 0u;
+        cnt[j] = j < NQ ? ccount[j] : 0u;
+        if (cnt[j] > (unsigned)a.cap) overflow = true;
+        c0[j] = 0;
+        if (j < NQ && (unsigned)tid < cnt[j] && cnt[j] <= (unsigned)a.cap)
+            c0[j] = (jobs.cand + a.cand_off + ((int64_t)r * NQ + j) * a.cap)[tid];
+    }
+    if (tid < QMAX) { sh_min[tid] = QNONE; sh_next[tid] = QNONE; }
+    for (int i = tid; i < QMAX * QB1; i += QT3) (&h2[0][0])[i] = 0;
+    unsigned tot = hv[0] + hv[1] + hv[2] + hv[3];
+    unsigned incl = block_scan_incl<QT3>(tot, wtot), excl = incl - tot;
+    if (tid == QT3 - 1) sh_n = incl;
+    __syncthreads();
+    const unsigned n = sh_n;
+    if (n == 0) {                                          // nothing kept: K1 added nothing, K2 returned early
+        if (tid < NQ) a.out[(int64_t)tid * a.R + r] = NAN;
+        return;
+    }
+    for (int j = 0; j < NQ; ++j)
+        locate<BPT>(hv, excl, incl, (unsigned)floorf(a.q[j] * (float)(n - 1)), &sh_bin0[j], &sh_kk[j]);
+    // level two: the 10 bits below, from the histograms K2 accumulated (rank inside the first-level bin = sh_kk)
+#pragma unroll
+    for (int j = 0; j < QMAX; ++j) {
+        if (j < NQ) {
+            const unsigned one[1] = {h1v[j]};
+            incl = block_scan_incl<QT3>(h1v[j], wtot);     // its barriers also publish sh_kk[j] of the level above
+            const unsigned lo = sh_kk[j];
+            __syncthreads();                               // everyone has read sh_kk[j] before it is rewritten
+            locate<1>(one, incl - h1v[j], incl, lo, &sh_bin1[j], &sh_kk[j]);
+        }
+    }
+    __syncthreads();
+    unsigned pre[QMAX], mn[QMAX];
+#pragma unroll
+    for (int j = 0; j < QMAX; ++j) {
+        pre[j] = j < NQ ? ((sh_bin0[j] << 10) | sh_bin1[j]) : QNONE;
+        mn[j] = QNONE;
+    }
+    // level three for quantile j (j is a compile-time index wherever this is used)
+#define CP2_Q_VISIT(k, j)                                                                   \
+    do {                                                                                    \
+        const unsigned top_ = (k) >> 10;                                                    \
+        if (top_ == pre[j]) atomicAdd(&h2[j][(k) & (QB1 - 1)], 1u);                         \
+        else if (top_ > pre[j]) mn[j] = min(mn[j], (k)); /* larger key, same first bin */   \
+    } while (0)
+    if (!overflow) {
+#pragma unroll
+        for (int j = 0; j < QMAX; ++j) {
+            if (j < NQ) {
+                const unsigned* src = jobs.cand + a.cand_off + ((int64_t)r * NQ + j) * a.cap;
+                if ((unsigned)tid < cnt[j]) CP2_Q_VISIT(c0[j], j);
+                for (unsigned i = tid + QT3; i < cnt[j]; i += QT3) { const unsigned k = src[i]; CP2_Q_VISIT(k, j); }
+            }
+        }
+    } else {                                               // a candidate list overflowed: the row itself, filtered
+        for_each_kept<QT3>(a, r, 0, a.N, [&](unsigned k) {
+#pragma unroll
+            for (int j = 0; j < QMAX; ++j)
+                if (j < NQ && (k >> 20) == (pre[j] >> 10)) CP2_Q_VISIT(k, j);
+        });
+    }
+#undef CP2_Q_VISIT
+#pragma unroll
+    for (int j = 0; j < QMAX; ++j) {
+        unsigned m = mn[j];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, off, 64));
+        if ((tid & 63) == 0 && m != QNONE) atomicMin(&sh_min[j], m);
+    }
+    __syncthreads();
+    for (int j = 0; j < NQ; ++j) {
+        const unsigned hvj = h2[j][tid];
+        const unsigned one[1] = {hvj};
+        incl = block_scan_incl<QT3>(hvj, wtot);
+        const unsigned lo = sh_kk[j];
+        __syncthreads();
+        locate<1>(one, incl - hvj, incl, lo, &sh_bin2[j], &sh_kk[j]);
+        __syncthreads();
+        // the next non-empty bin above the selected one (the partner when the selected key is not repeated)
+        if (hvj != 0 && (unsigned)tid > sh_bin2[j]) atomicMin(&sh_next[j], (unsigned)tid);
+    }
+    __syncthreads();
     if (tid < NQ) {
         const int j = tid;
-        const unsigned n = sh_n;
         const float rank = a.q[j] * (float)(n - 1);
         const float lo_f = floorf(rank), w = rank - lo_f;
-        const unsigned key_lo = sh_prefix[j];
+        const unsigned p22 = (sh_bin0[j] << 10) | sh_bin1[j];
+        const unsigned key_lo = (p22 << 10) | sh_bin2[j];
         const float v_lo = key2f(key_lo);
         float v_hi = v_lo;
         if (w != 0.f) {
-            const unsigned mult = hist[j][key_lo & (QB1 - 1)];
-            if (sh_k[j] + 1 >= mult) {                     // the element of rank lo + 1 is a larger key
-                if (sh_next[j] != 0xFFFFFFFFu) v_hi = key2f((key_lo & ~(unsigned)(QB1 - 1)) | sh_next[j]);
-                else if (sh_min[j] != 0xFFFFFFFFu) v_hi = key2f(sh_min[j]);
+            const unsigned mult = h2[j][sh_bin2[j]];
+            if (sh_kk[j] + 1 >= mult) {                    // the element of rank lo + 1 is a larger key
+                const unsigned ab = above[j];
+                if (sh_next[j] != QNONE) v_hi = key2f((p22 << 10) | sh_next[j]);
+                else if (sh_min[j] != QNONE) v_hi = key2f(sh_min[j]);
+                else if (ab != 0u) v_hi = key2f(~ab);
             }
         }
         const float d = v_hi - v_lo;                         // at::lerp: w < 0.5 ? a + w*(b-a) : b - (b-a)*(1-w)
         a.out[(int64_t)j * a.R + r] = (w < 0.5f) ? v_lo + w * d : v_hi - d * (1.f - w);
     }
-#undef CP2_Q_FOREACH
+    __syncthreads();
+    // leave the row's workspace zeroed for the next call (stream order makes it visible)
+    reinterpret_cast<uint4*>(g0)[tid] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int j = 0; j < QMAX; ++j) g1[j * QB1 + tid] = 0u;
+    if (tid < QMAX) { ccount[tid] = 0; above[tid] = 0; }
 }
 
 static int quant_check(const QuantArgs& a) {
@@ -222,48 +493,88 @@ static int quant_check(const QuantArgs& a) {
     if (a.R <= 0 || a.N <= 0 || a.NQ <= 0) return CP2_ERR_SHAPE;
     if (a.NQ > QMAX) return CP2_ERR_UNSUPPORTED;
     if (a.want >= 0 && (!a.mask_a || !a.mask_b || a.P <= 0 || (int64_t)a.P * a.P != a.N)) return CP2_ERR_SHAPE;
-    if (a.want >= 0 && a.P > 8192) return CP2_ERR_UNSUPPORTED;
     return CP2_OK;
 }
 
-static int quant_launch(const QuantJobs& jobs, int njobs, hipStream_t stream) {
-    size_t lds = 0;
+static int quant_cap(int N) {
+    int cap = N / 16;
+    if (cap < 4096) cap = 4096;
+    if (cap > N) cap = N < 1 ? 1 : N;
+    return (cap + 3) & ~3;
+}
+
+// words (4 bytes) of workspace for the given jobs
+static int64_t quant_ws_words(int njobs, const int* R, const int* N, int NQ) {
+    int64_t rows = 0, cand = 0;
     for (int j = 0; j < njobs; ++j) {
-        int rc = quant_check(jobs.job[j]);
+        if (R[j] <= 0 || N[j] <= 0) continue;
+        rows += R[j];
+        cand += (int64_t)R[j] * NQ * quant_cap(N[j]);
+    }
+    return rows * QROW_WORDS + cand;
+}
+
+CP2_API int64_t cp2_quantiles_workspace_bytes(int njobs, const int* R, const int* N, int NQ) {
+    if (njobs <= 0 || njobs > QJOBS || !R || !N || NQ <= 0 || NQ > QMAX) return 0;
+    return 4 * quant_ws_words(njobs, R, N, NQ);
+}
+
+static int quant_launch(QuantJobs& jobs, int njobs, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+    if (!workspace) return CP2_ERR_NULL;
+    if (!cp2_aligned16(workspace)) return CP2_ERR_ALIGN;
+    int rows = 0, chunks = 0;
+    int64_t cand = 0;
+    int Rs[QJOBS], Ns[QJOBS];
+    for (int j = 0; j < njobs; ++j) {
+        QuantArgs& a = jobs.job[j];
+        int rc = quant_check(a);
         if (rc) return rc;
-        const size_t l = jobs.job[j].want >= 0 ? 2 * (size_t)jobs.job[j].P * sizeof(float) : 0;
-        if (l > lds) lds = l;
+        a.chunks = cp2_cdiv(a.N, QCHUNK);
+        a.cap = quant_cap(a.N);
+        a.cand_off = cand;
+        cand += (int64_t)a.R * a.NQ * a.cap;
+        jobs.first_row[j] = rows;
+        jobs.first_chunk[j] = chunks;
+        rows += a.R;
+        if ((int64_t)chunks + (int64_t)a.R * a.chunks > 0x7fffffff) return CP2_ERR_UNSUPPORTED;
+        chunks += a.R * a.chunks;
+        Rs[j] = a.R; Ns[j] = a.N;
     }
-    if (lds > 16384) {
-        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(quantiles_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e_ != hipSuccess) return (int)e_;
-    }
-    CP2_LAUNCH_PROFILED(quantiles_kernel, dim3(jobs.first_row[njobs]), dim3(QT), lds, stream, jobs);
+    for (int j = njobs; j <= QJOBS; ++j) { jobs.first_row[j] = rows; jobs.first_chunk[j] = chunks; }
+    if (4 * quant_ws_words(njobs, Rs, Ns, jobs.job[0].NQ) > workspace_bytes) return CP2_ERR_SHAPE;
+    unsigned* w = static_cast<unsigned*>(workspace);
+    jobs.hist0 = w;
+    jobs.hist1 = jobs.hist0 + (int64_t)rows * QB0;
+    jobs.ccount = jobs.hist1 + (int64_t)rows * QMAX * QB1;
+    jobs.above = jobs.ccount + (int64_t)rows * QMAX;
+    jobs.cand = jobs.above + (int64_t)rows * QMAX;
+    // measurement aid: the armed start event rides on K1, the stop event on K3 (elapsed = the three launches)
+    const Cp2LaunchEvents ev = cp2_next_events;
+    cp2_next_events = Cp2LaunchEvents{};
+    if (ev.start) hipExtLaunchKernelGGL(quantile_hist_kernel, dim3(chunks), dim3(QT1), 0, stream, ev.start, nullptr, 0, jobs);
+    else hipLaunchKernelGGL(quantile_hist_kernel, dim3(chunks), dim3(QT1), 0, stream, jobs);
+    hipLaunchKernelGGL(quantile_compact_kernel, dim3(chunks), dim3(QT1), 0, stream, jobs);
+    if (ev.stop) hipExtLaunchKernelGGL(quantile_final_kernel, dim3(rows), dim3(QT3), 0, stream, nullptr, ev.stop, 0, jobs);
+    else hipLaunchKernelGGL(quantile_final_kernel, dim3(rows), dim3(QT3), 0, stream, jobs);
     return cp2_launch_status();
 }
 
 CP2_API int cp2_masked_quantiles(const float* x, int64_t stride_row, int64_t stride_elem, int R, int N,
                                  const float* mask_a, const float* mask_b, int P, int want, const float* q, int NQ,
-                                 float* out, void* stream) {
+                                 float* out, void* workspace, int64_t workspace_bytes, void* stream) {
     QuantJobs jobs{};
-    jobs.job[0] = QuantArgs{x, stride_row, stride_elem, N, mask_a, mask_b, P, want, q, NQ, out, R};
-    for (int j = 1; j <= QJOBS; ++j) jobs.first_row[j] = R > 0 ? R : 0;
-    return quant_launch(jobs, 1, cp2_stream(stream));
+    jobs.job[0] = QuantArgs{x, stride_row, stride_elem, N, mask_a, mask_b, P, want, q, NQ, out, R, 0, 0, 0};
+    return quant_launch(jobs, 1, workspace, workspace_bytes, cp2_stream(stream));
 }
 
 CP2_API int cp2_masked_quantiles_multi(int njobs, const float* const* x, const int64_t* stride_row, const int64_t* stride_elem,
                                        const int* R, const int* N, const float* const* mask_a, const float* const* mask_b,
-                                       const int* P, const int* want, const float* q, int NQ, float* const* out, void* stream) {
+                                       const int* P, const int* want, const float* q, int NQ, float* const* out,
+                                       void* workspace, int64_t workspace_bytes, void* stream) {
     if (njobs <= 0 || njobs > QJOBS) return CP2_ERR_UNSUPPORTED;
     if (!x || !stride_row || !stride_elem || !R || !N || !mask_a || !mask_b || !P || !want || !out) return CP2_ERR_NULL;
     QuantJobs jobs{};
-    int rows = 0;
-    for (int j = 0; j < njobs; ++j) {
-        jobs.job[j] = QuantArgs{x[j], stride_row[j], stride_elem[j], N[j], mask_a[j], mask_b[j], P[j], want[j], q, NQ, out[j], R[j]};
-        jobs.first_row[j] = rows;
-        rows += R[j] > 0 ? R[j] : 0;
-    }
-    for (int j = njobs; j <= QJOBS; ++j) jobs.first_row[j] = rows;
-    return quant_launch(jobs, njobs, cp2_stream(stream));
+    for (int j = 0; j < njobs; ++j)
+        jobs.job[j] = QuantArgs{x[j], stride_row[j], stride_elem[j], N[j], mask_a[j], mask_b[j], P[j], want[j], q, NQ, out[j], R[j], 0, 0, 0};
+    return quant_launch(jobs, njobs, workspace, workspace_bytes, cp2_stream(stream));
 }

@@ -523,27 +523,38 @@ def _quartile_tensor(device) -> torch.Tensor:
     return _QUARTILES[key]
 
 
+_QUANT_WS = {}
+
+
+def _quant_workspace(dev, R, N, NQ):
+    """Zeroed workspace of cp2_masked_quantiles(_multi), one per (device, shape signature): the kernels leave it zero,
+    so it is allocated and cleared once (a few MB at the training shapes) and re-used by every later step."""
+    import ctypes
+    key = (dev.index, tuple(R), tuple(N), NQ)
+    ws = _QUANT_WS.get(key)
+    if ws is None:
+        n = len(R)
+        I32 = ctypes.c_int * n
+        nbytes = _lib.load().cp2_quantiles_workspace_bytes(n, I32(*R), I32(*N), NQ)
+        if nbytes <= 0:
+            raise ValueError("masked_quantiles: bad job shapes")
+        if len(_QUANT_WS) >= 16:                      # tests sweep many shapes: do not hoard
+            _QUANT_WS.clear()
+        ws = _QUANT_WS[key] = torch.zeros(nbytes // 4, dtype=torch.int32, device=dev)
+    return ws
+
+
 def masked_quantiles(x: torch.Tensor, stride_row: int, stride_elem: int, R: int, N: int, q: Optional[torch.Tensor] = None,
                      mask_a: Optional[torch.Tensor] = None, mask_b: Optional[torch.Tensor] = None, want: int = -1) -> torch.Tensor:
     """out[j, r] = nanquantile of the kept elements of row r at q[j] (linear interpolation), no sort.
     want = -1 keeps everything; 1 / 0 keep the positive / negative pairs of a [P,P] logit map per row
     (reference tools/correlation_mapping.py:16-53, builder.py:1399-1406)."""
-    lib = _lib.load()
-    if q is None:
-        q = _quartile_tensor(x.device)
-    out = torch.empty((q.numel(), R), dtype=torch.float32, device=x.device)
-    P = mask_a.shape[1] if mask_a is not None else 0
-    if not x.is_cuda or x.dtype != torch.float32:
-        raise _lib.Cp2LibraryError("masked_quantiles: x must be a float32 GPU tensor")
-    rc = lib.cp2_masked_quantiles(x.data_ptr(), stride_row, stride_elem, R, N, _opt(mask_a, "mask_a", torch.float32),
-                                  _opt(mask_b, "mask_b", torch.float32), P, want, _dev(q, "q", torch.float32), q.numel(),
-                                  out.data_ptr(), _stream())
-    _lib.check(rc, "cp2_masked_quantiles")
-    return out
+    return masked_quantiles_multi([dict(x=x, stride_row=stride_row, stride_elem=stride_elem, R=R, N=N, mask_a=mask_a,
+                                        mask_b=mask_b, want=want)], q)[0]
 
 
 def masked_quantiles_multi(jobs, q: Optional[torch.Tensor] = None):
-    """Several masked_quantiles problems in one launch.  jobs: list of dicts with the keyword arguments of
+    """Several masked_quantiles problems in one call.  jobs: list of dicts with the keyword arguments of
     masked_quantiles (x, stride_row, stride_elem, R, N, mask_a, mask_b, want); returns the list of outputs."""
     import ctypes
     lib = _lib.load()
@@ -556,15 +567,17 @@ def masked_quantiles_multi(jobs, q: Optional[torch.Tensor] = None):
     I64, I32 = ctypes.c_int64 * n, ctypes.c_int * n
     for j in jobs:
         if not j["x"].is_cuda or j["x"].dtype != torch.float32:
-            raise _lib.Cp2LibraryError("masked_quantiles_multi: x must be a float32 GPU tensor")
+            raise _lib.Cp2LibraryError("masked_quantiles: x must be a float32 GPU tensor")
     ma = [_opt(j.get("mask_a"), "mask_a", torch.float32) for j in jobs]
     mb = [_opt(j.get("mask_b"), "mask_b", torch.float32) for j in jobs]
+    ws = _quant_workspace(dev, [j["R"] for j in jobs], [j["N"] for j in jobs], q.numel())
     _profile("quantiles")
     rc = lib.cp2_masked_quantiles_multi(
         n, P_(*[j["x"].data_ptr() for j in jobs]), I64(*[j["stride_row"] for j in jobs]), I64(*[j["stride_elem"] for j in jobs]),
         I32(*[j["R"] for j in jobs]), I32(*[j["N"] for j in jobs]), P_(*ma), P_(*mb),
         I32(*[(j["mask_a"].shape[1] if j.get("mask_a") is not None else 0) for j in jobs]),
-        I32(*[j.get("want", -1) for j in jobs]), _dev(q, "q", torch.float32), q.numel(), P_(*[o.data_ptr() for o in outs]), _stream())
+        I32(*[j.get("want", -1) for j in jobs]), _dev(q, "q", torch.float32), q.numel(), P_(*[o.data_ptr() for o in outs]),
+        ws.data_ptr(), ws.numel() * 4, _stream())
     _lib.check(rc, "cp2_masked_quantiles_multi")
     return outs
 

@@ -191,12 +191,17 @@ int cp2_dense_infonce_bwd(const float* q_dense, const float* k_dense, const floa
  * (the reference's positive / negative dense scores).  q: device float[NQ]; out: [NQ,R].  NaN when nothing is kept. */
 int cp2_masked_quantiles(const float* x, int64_t stride_row, int64_t stride_elem, int R, int N,
                          const float* mask_a, const float* mask_b, int P, int want, const float* q, int NQ,
-                         float* out, void* stream);
-/* Up to 4 such problems in ONE launch (one workgroup per row of every job; NQ <= 4 quantiles q shared by all jobs).
- * Every argument of cp2_masked_quantiles becomes a HOST array of njobs entries (device pointers inside). */
+                         float* out, void* workspace, int64_t workspace_bytes, void* stream);
+/* Up to 4 such problems in one call of three launches (rows cut into 8192-element chunks: first-level histogram,
+ * candidate compaction, per-row select; NQ <= 4 quantiles q shared by all jobs).  Every argument of
+ * cp2_masked_quantiles becomes a HOST array of njobs entries (device pointers inside).
+ * workspace: device memory of cp2_quantiles_workspace_bytes(njobs, R, N, NQ) bytes, 16-byte aligned, ZERO before the
+ * first call; every call leaves it zero again, so the same buffer serves every later call with the SAME (R, N, NQ). */
+int64_t cp2_quantiles_workspace_bytes(int njobs, const int* R, const int* N, int NQ);
 int cp2_masked_quantiles_multi(int njobs, const float* const* x, const int64_t* stride_row, const int64_t* stride_elem,
                                const int* R, const int* N, const float* const* mask_a, const float* const* mask_b,
-                               const int* P, const int* want, const float* q, int NQ, float* const* out, void* stream);
+                               const int* P, const int* want, const float* q, int NQ, float* const* out,
+                               void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- f1: on-device two-crop augmentation + background erasing --- loader.py:39-43,50-118; main.py:204-225
  * One launch makes B output samples from a dataset resident in device memory: src [N,3,Hs,Ws] fp32 in [0,1]

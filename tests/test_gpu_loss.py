@@ -252,7 +252,35 @@ def test_masked_quantiles_bit_exact_vs_torch():
             xt = x.t().contiguous()                             # key-major storage, as lnegT
             got_t = ops.masked_quantiles(xt.to(DEV), 1, R, R, N, q=qs.to(DEV))
             assert torch.equal(got_t.cpu(), want), (R, N, "strided")
+    # chunked rows: many chunks per row, all-equal rows, a narrow band (every element in one first-level bin: the
+    # candidate lists overflow and the select re-reads the row), +-inf, and a workspace re-used by consecutive calls
+    for R, N, kind in ((2, 3_000_000, "normal"), (3, 70_001, "const"), (2, 200_003, "band"), (2, 50_000, "inf")):
+        x = torch.randn(R, N, generator=gen) * 0.09
+        if kind == "const":
+            x[:] = -0.25
+            x[2, 5] = 1.0
+        elif kind == "band":
+            x = 0.5 + torch.rand(R, N, generator=gen) * 1e-4
+        elif kind == "inf":
+            x[0, ::7] = float("inf")
+            x[1, ::5] = float("-inf")
+        qs = torch.tensor([0.25, 0.5, 0.75])
+        want = torch.nanquantile(x, qs, dim=1)
+        xd = x.to(DEV)
+        for _ in range(2):
+            got = ops.masked_quantiles(xd, N, 1, R, N, q=qs.to(DEV))
+            assert np.array_equal(got.cpu().numpy(), want.numpy(), equal_nan=True), (R, N, kind)
     # masked form against the oracle's dense statistics
+    for B, P in ((2, 260), (2, 130)):                           # P % 4 == 0 and != 0, several chunks per row
+        logits = torch.randn(B, P, P, generator=gen) * 0.1
+        ma = (torch.rand(B, P, generator=gen) > 0.4).float()
+        mb = (torch.rand(B, P, generator=gen) > 0.5).float()
+        st = O.dense_loss_stats(logits, ma[:, :, None] * mb[:, None, :])
+        jobs = [dict(x=logits.to(DEV), stride_row=P * P, stride_elem=1, R=B, N=P * P, mask_a=ma.to(DEV), mask_b=mb.to(DEV), want=w)
+                for w in (1, 0)]
+        pos, neg = ops.masked_quantiles_multi(jobs)
+        assert np.array_equal(pos.cpu().numpy(), st["positive"]["quartiles"].numpy(), equal_nan=True)
+        assert np.array_equal(neg.cpu().numpy(), st["negative"]["quartiles"].numpy(), equal_nan=True)
     B, P = 3, 37
     logits = torch.randn(B, P, P, generator=gen)
     ma = (torch.rand(B, P, generator=gen) > 0.4).float()
