@@ -493,6 +493,9 @@ class MODEL(nn.Module):
         iou, iou_masked = ops.corr_iou(region_a, region_b, mask_a, mask_b)      # logged per epoch, stays on device
         self.correlation_ious.append(iou)
         self.masked_correlation_ious.append(iou_masked)
+        if len(self.correlation_ious) >= 1024:              # keep the python lists short (device-side concatenation, no sync)
+            self.correlation_ious[:] = [torch.cat(self.correlation_ious)]
+            self.masked_correlation_ious[:] = [torch.cat(self.masked_correlation_ious)]
 
         # The key branch (EMA -> shuffle-BN all-gather -> key encoder -> un-shuffle all-gather) does not depend on the
         # query encoder (reference order builder.py:1260-1277 is serial).  overlap_key_branch:
@@ -644,7 +647,9 @@ class MODEL(nn.Module):
         stay on the device; flush_logs() moves everything queued so far in one copy."""
         names = list(scalars)
         self._pending_logs.append((step, n, names, torch.stack([scalars[k].detach().float().reshape(()) for k in names])))
-        if self.sync_logs_every and len(self._pending_logs) >= self.sync_logs_every:
+        # bounded even if the caller never flushes: one batched copy every `sync_logs_every` (default: 4096) records
+        limit = self.sync_logs_every or 4096
+        if len(self._pending_logs) >= limit and not torch.cuda.is_current_stream_capturing():
             self.flush_logs()
 
     def flush_logs(self):

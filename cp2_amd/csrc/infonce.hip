@@ -702,7 +702,7 @@ CP2_API int cp2_rowkey_infonce_fwd(const float* rows, int RP, int64_t r_sn, int6
     if (rowkey_use_small(R, K) && rowkey_small_rows_ok(rows, r_sn, r_sx, r_sc, keys)) {
         RowKeyArgs sa{rows, RP, r_sn, r_sx, r_sc, R, keys, K, extras, NE, 1.0f / temperature, 0,
                       part_m, part_s, part_cnt, part_U, lnegT, ln_sk, ln_sr};
-        return rowkey_small_launch(sa, nsplit, part_U != nullptr, cp2_stream(stream));
+        return rowkey_small_launch(sa, nsplit, part_U != nullptr, precision == 2, cp2_stream(stream));
     }
     int WR, WK;
     rowkey_shape(R, &WR, &WK);

@@ -99,16 +99,18 @@ struct Conv1x1Fn : public torch::autograd::Function<Conv1x1Fn> {
                                    c10::hip::getCurrentHIPStream().stream());
             TORCH_CHECK(rc == 0, "cp2_wgrad1x1 failed: ", rc);
         }
+        // Bias gradient = column sums of dy, as two block-local reductions ([N, H*W, co] over H*W, then over N) in fp32.
+        // ATen's own bias gradient for channels-last (one sum over N, H, W) is a multi-block reduction with a zero-filled
+        // semaphore: under whole-step hipGraph replay it returned a non-finite element from the second replay on
+        // (tools/graph_verify_probe.py) -- the same "zero-fill, then accumulate" shape as the
+        // MIOpen weight-gradient solvers that failed there.
+        if (need_db) db = dy.permute({0, 2, 3, 1}).reshape({N, H * W, co}).sum(1, false, at::kFloat).sum(0);
         const bool rest_dx = need_dx && !dx.defined(), rest_dw = need_dw && !dw.defined();
-        if (rest_dx || rest_dw || need_db) {
-            c10::optional<at::IntArrayRef> bias_sizes;
-            const std::vector<int64_t> bs{co};
-            if (need_db) bias_sizes = at::IntArrayRef(bs);
-            const auto r = at::convolution_backward(dy, x, w, bias_sizes, {1, 1}, {0, 0}, {1, 1}, false, {0, 0}, 1,
-                                                    {rest_dx, rest_dw, need_db});
+        if (rest_dx || rest_dw) {
+            const auto r = at::convolution_backward(dy, x, w, c10::nullopt, {1, 1}, {0, 0}, {1, 1}, false, {0, 0}, 1,
+                                                    {rest_dx, rest_dw, false});
             if (rest_dx) dx = std::get<0>(r);
             if (rest_dw) dw = grad_to_master(std::get<1>(r), ctx->saved_data["wshape"].toIntVector(), ctx->saved_data["wstride"].toIntVector());
-            if (need_db) db = std::get<2>(r).to(at::kFloat);
         }
         return {dx, dw, at::Tensor(), db, at::Tensor(), at::Tensor(), at::Tensor()};
     }

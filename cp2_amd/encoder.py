@@ -141,17 +141,15 @@ class _Conv1x1Fn(torch.autograd.Function):
         dw = None
         if need_dw and _Conv1x1Fn.hip_wgrad and _bn_ops.wgrad1x1_supported(co, C):
             dw = _bn_ops.wgrad1x1(dy, x)          # deterministic split-K on the matrix cores, fp32 result (csrc/wgrad.hip)
-        want = [need_dx and dx is None, need_dw and dw is None, bool(need_db)]
+        # bias gradient as two block-local fp32 reductions (no multi-block semaphore reduction: see autograd_ext.cpp)
+        db = dy.permute(0, 2, 3, 1).reshape(N, H * W, co).sum(1, dtype=torch.float32).sum(0) if need_db else None
+        want = [need_dx and dx is None, need_dw and dw is None, False]
         if any(want):
-            rest = torch.ops.aten.convolution_backward(dy, x, w, [co] if need_db else None, [1, 1], [0, 0], [1, 1], False,
-                                                       [0, 0], 1, want)
+            rest = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, want)
             if want[0]:
                 dx = rest[0]
             if want[1]:
                 dw = rest[1].to(torch.float32)
-            db = rest[2].to(torch.float32) if need_db else None
-        else:
-            db = None
         return dx, dw, None, db, None, None
 
 

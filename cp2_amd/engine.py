@@ -150,6 +150,10 @@ class TrainStep:
             inner._pending_logs.append((self.step_idx, n, names, vals.clone()))
         for src, dst in getattr(self, "_iou_templates", ()):
             dst.append(src.clone())
+            if len(dst) >= 1024:
+                dst[:] = [torch.cat(dst)]
+        if len(inner._pending_logs) >= (inner.sync_logs_every or 4096):
+            inner.flush_logs()
         for m in getattr(self, "_bn_modules", ()):
             m._pending_batches += 1
 

@@ -392,10 +392,17 @@ def rowkey_infonce(rows: torch.Tensor, row_layout: Tuple[int, int, int, int], R:
     grad_scale None -> forward only; else drows (same layout, allocated like `drows_like` or
     `rows`) and dE carry grad_scale * d(sum_r loss_r)/d(rows, extras).
     precision: "f32" (exact fp32 on the f32-input MFMA), "bf16x3" (split-bf16, logits within 3e-5, ~3x faster when
-    MFMA-bound) or "auto" = bf16x3 from 1024 rows up (the DenseCL per-pixel case), f32 below."""
-    if precision not in ("auto", "f32", "bf16x3"):
+    MFMA-bound), "bf16x6" (at most 32 rows: every operand as three bf16 parts, six products -- logits within 2e-7 of
+    the exact fp32 value; measured no faster than "f32" at 32 x 65536, where the kernel waits for the queue stream, so
+    it is an option, not the default) or "auto" = bf16x3 from 1024 rows up (the DenseCL per-pixel case), f32 below."""
+    if precision not in ("auto", "f32", "bf16x3", "bf16x6"):
         raise ValueError(f"precision {precision!r}")
-    prec = 1 if (precision == "bf16x3" or (precision == "auto" and R >= 1024)) else 0
+    if precision == "bf16x6" and R > 32:
+        raise ValueError("precision 'bf16x6' is the small-R kernel's mode (R <= 32)")
+    if precision == "auto":
+        prec = 1 if R >= 1024 else 0
+    else:
+        prec = {"f32": 0, "bf16x3": 1, "bf16x6": 2}[precision]
     lib = _lib.load()
     C, K = keys.shape
     RP, sn, sx, sc = row_layout

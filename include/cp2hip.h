@@ -131,6 +131,8 @@ int cp2_feat_bwd(const float* dense, const float* inv_norm, const float* mask, c
  * part_cnt [nsplit,R] int32, part_U [nsplit,C,R] (NULL: no gradient), lnegT: NULL, or the raw logits rows.keys as
  * [K,R] (lneg_row_major = 0) or [R,K] (lneg_row_major = 1, the layout cp2_masked_quantiles reads fastest).
  * precision 0: f32-input MFMA (exact fp32 fma chains, logits within ~1e-6 of the reference);
+ * precision 2: R <= 32 only: three-way bf16 split of both operands, six products on bf16 MFMA with fp32 accumulation
+ *              (logits within 2e-7 of the exact fp32 value); other R: as precision 0;
  * precision 1: split-bf16 (hi*hi + hi*lo + lo*hi on bf16 MFMA, fp32 accumulate; logits within 3e-5) -- used when
  *              R > 64, otherwise the f32 kernel runs regardless.  keys_split: NULL, or a workspace of 4*C*K bf16
  *              (16-byte aligned, K % 8 == 0) that receives the hi/lo split of the queue in both layouts once per call;

@@ -42,7 +42,8 @@ class A:
 
 
 OPT = os.environ.get("OPT", "none")                                # none: gradients only | fused: torch fused SGD | flat: FlatSGD
-if OPT != "none":
+LR0 = os.environ.get("LR0", "0") == "1"                            # optimizer kernel in the graph, but lr = wd = 0: parameters stay
+if OPT != "none" and not LR0:                                      # put, so every replay must reproduce the eager gradients
     A.lr, A.weight_decay = 0.03, 1e-4
 opt = make_optimizer(list(model.parameters()), A, dev, capturable=True, model=model if OPT == "flat" else None)
 if OPT == "none":
@@ -50,7 +51,7 @@ if OPT == "none":
 # dirty the caching allocator's free blocks, as a long run would
 junk = [torch.full((1 << 26,), float("nan"), device=dev) for _ in range(24)]
 torch.cuda.synchronize(); del junk
-runner = TrainStep(model, opt, use_graph=True, warmup_steps=3, verify=False)
+runner = TrainStep(model, opt, use_graph=True, warmup_steps=3, verify=os.environ.get("VERIFY", "0") == "1", reverify_every=0)
 batch = synthetic.make_batch(32, 224, 224, dev, seed=0)
 names = [n for n, p in model.named_parameters() if p.requires_grad]
 params = [p for n, p in model.named_parameters() if p.requires_grad]
@@ -71,6 +72,8 @@ for i in range(int(os.environ.get("STEPS", "14"))):
         if not (err == err) or err > (0.05 if FROZEN else 10.0) * r.norm().item() + 1e-6:
             bad.append((n, tuple(g.shape), f"{err:.2e}/{r.norm().item():.2e}"))
     nonfinite = [n for n, p in model.named_parameters() if not torch.isfinite(p).all()]
-    if OPT != "none":
+    if OPT != "none" and not LR0:
         bad = [b for b in bad if b[2].startswith("nan") or b[2].startswith("inf")]
-    print(f"step {i} {kind} loss {float(loss):.4f} bad-gradients {len(bad)}", bad[:6], "non-finite params", len(nonfinite), nonfinite[:4], flush=True)
+    worst = max(((g - r).norm().item() / (r.norm().item() + 1e-12), n) for n, g, r in zip(names, grads, ref) if g is not None and r is not None)
+    print(f"step {i} {kind} loss {float(loss):.4f} bad-gradients {len(bad)}", bad[:6], "non-finite params", len(nonfinite), nonfinite[:4],
+          f"worst rel err {worst[0]:.3e} at {worst[1]}", flush=True)
