@@ -488,6 +488,172 @@ __global__ __launch_bounds__(QT3) void quantile_final_kernel(QuantJobs jobs) {
     if (tid < QMAX) { ccount[tid] = 0; above[tid] = 0; }
 }
 
+// ---- small rows (N <= QROW_MAX): ONE launch, one workgroup per row through all three levels (round 1 / early round 2).
+// At the training step's shapes (32 x 65536 queue logits + 2 x 32 x 196^2 dense pairs) three chunked launches pay
+// their per-workgroup set-up and two launch boundaries for 18 MB of data, and the logits of a freshly initialised
+// encoder lie in a band so narrow that a 12-bit float prefix holds most of a row (the candidate lists overflow):
+// measured inside the step 74 us for the three launches against 66 us for this kernel.  The chunked form above is for
+// rows a single CU cannot stream (BASELINE config 4: 16.7 M elements per row).
+constexpr int QROW_MAX = CP2_QUANTILES_ROW_MAX;
+__global__ __launch_bounds__(QT3) void quantiles_row_kernel(QuantJobs jobs) {
+    int jsel = 0;
+#pragma unroll
+    for (int j = 1; j < QJOBS; ++j) jsel += ((int)blockIdx.x >= jobs.first_row[j]) ? 1 : 0;
+    const QuantArgs& a = jobs.job[jsel];
+    extern __shared__ __attribute__((aligned(16))) unsigned char q_smem[];
+    __shared__ unsigned hist0[QB0];
+    __shared__ unsigned hist[QMAX][QB1];
+    __shared__ unsigned wtot[16];
+    __shared__ unsigned sh_prefix[QMAX], sh_k[QMAX], sh_min[QMAX], sh_next[QMAX], sh_n;
+    float* lma = reinterpret_cast<float*>(q_smem);
+    float* lmb = lma + (a.want >= 0 ? a.P : 0);
+    const int r = (int)blockIdx.x - jobs.first_row[jsel], tid = threadIdx.x, NQ = a.NQ;
+    const float* row = a.x + (int64_t)r * a.s_row;
+    const bool masked = a.want >= 0;
+    if (masked) {
+        for (int i = tid; i < a.P; i += QT3) { lma[i] = a.mask_a[(int64_t)r * a.P + i]; lmb[i] = a.mask_b[(int64_t)r * a.P + i]; }
+    }
+    for (int i = tid; i < QB0; i += QT3) hist0[i] = 0;
+    __syncthreads();
+    const bool vec = a.s_elem == 1 && ((reinterpret_cast<uintptr_t>(row) & 15u) == 0);
+    auto keep_at = [&](int x, int y, float v) -> bool {
+        if (v != v) return false;                          // nanquantile ignores NaN
+        if (!masked) return true;
+        return ((lma[x] * lmb[y]) != 0.f) == (a.want != 0);
+    };
+    // Visit every kept element of the row once: 16-byte loads when the row is contiguous, four loads in flight otherwise.
+#define CP2_Q_FOREACH(BODY)                                                                              \
+    if (vec) {                                                                                           \
+        const int n4 = (a.N + 3) >> 2;                                                                   \
+        for (int j4 = tid; j4 < n4; j4 += 4 * QT3) {                                                      \
+            float4 t4[4];                                                                                \
+            _Pragma("unroll") for (int g = 0; g < 4; ++g) {      /* four 16-byte loads in flight */       \
+                const int i0 = (j4 + g * QT3) * 4;                                                        \
+                if (i0 + 3 < a.N) {                                                                      \
+                    t4[g] = *reinterpret_cast<const float4*>(row + i0);                                  \
+                } else {                                                                                 \
+                    t4[g].x = (i0 + 0 < a.N) ? row[i0 + 0] : NAN;                                        \
+                    t4[g].y = (i0 + 1 < a.N) ? row[i0 + 1] : NAN;                                        \
+                    t4[g].z = (i0 + 2 < a.N) ? row[i0 + 2] : NAN;                                        \
+                    t4[g].w = NAN;                                                                       \
+                }                                                                                        \
+            }                                                                                            \
+            _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                              \
+                const int i0 = (j4 + g * QT3) * 4;                                                        \
+                const float vv[4] = {t4[g].x, t4[g].y, t4[g].z, t4[g].w};                                \
+                int x_ = masked ? i0 / a.P : 0, y_ = masked ? i0 % a.P : 0;                              \
+                _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                          \
+                    const float v = vv[u];                                                               \
+                    if (keep_at(x_, y_, v)) { BODY }                                                     \
+                    if (masked && ++y_ >= a.P) { y_ = 0; ++x_; }                                         \
+                }                                                                                        \
+            }                                                                                            \
+        }                                                                                                \
+    } else {                                                                                             \
+        for (int i0 = tid; i0 < a.N; i0 += 4 * QT3) {                                                     \
+            float vv[4];                                                                                 \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                              \
+                const int i = i0 + u * QT3;                                                               \
+                vv[u] = i < a.N ? row[(int64_t)i * a.s_elem] : NAN;                                      \
+            }                                                                                            \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                              \
+                const int i = i0 + u * QT3;                                                               \
+                const float v = vv[u];                                                                   \
+                if (keep_at(masked ? i / a.P : 0, masked ? i % a.P : 0, v)) { BODY }                     \
+            }                                                                                            \
+        }                                                                                                \
+    }
+
+    // ---- pass 0: top 12 bits, one histogram for all quantiles (its total is n)
+    CP2_Q_FOREACH(atomicAdd(&hist0[f2key(v) >> 20], 1u);)
+    __syncthreads();
+    {
+        const unsigned h0 = hist0[4 * tid], h1 = hist0[4 * tid + 1], h2 = hist0[4 * tid + 2], h3 = hist0[4 * tid + 3];
+        const unsigned tot = h0 + h1 + h2 + h3;
+        const unsigned incl = block_scan_incl<QT3>(tot, wtot), excl = incl - tot;
+        if (tid == QT3 - 1) sh_n = incl;
+        __syncthreads();
+        const unsigned n = sh_n;
+        if (n == 0) {
+            if (tid < NQ) a.out[(int64_t)tid * a.R + r] = NAN;
+            return;
+        }
+        for (int j = 0; j < NQ; ++j) {
+            const unsigned lo = (unsigned)floorf(a.q[j] * (float)(n - 1));
+            if (lo >= excl && lo < incl) {
+                unsigned kk = lo - excl, b = 4 * tid;
+                if (kk >= h0) { kk -= h0; ++b; if (kk >= h1) { kk -= h1; ++b; if (kk >= h2) { kk -= h2; ++b; } } }
+                sh_prefix[j] = b;
+                sh_k[j] = kk;
+            }
+        }
+    }
+    // ---- passes 1 and 2: ten more bits each, one histogram per quantile
+    for (int pass = 1; pass <= 2; ++pass) {
+        for (int i = tid; i < QMAX * QB1; i += QT3) (&hist[0][0])[i] = 0;
+        if (tid < QMAX) { sh_min[tid] = 0xFFFFFFFFu; sh_next[tid] = 0xFFFFFFFFu; }
+        __syncthreads();
+        unsigned pre[QMAX], mn[QMAX];
+#pragma unroll
+        for (int j = 0; j < QMAX; ++j) { pre[j] = j < NQ ? sh_prefix[j] : 0xFFFFFFFFu; mn[j] = 0xFFFFFFFFu; }
+        const int sh = pass == 1 ? 20 : 10;
+        CP2_Q_FOREACH(
+            const unsigned k = f2key(v);
+            const unsigned top = k >> sh;
+            const unsigned bin = (k >> (sh - 10)) & (QB1 - 1);
+            _Pragma("unroll") for (int j = 0; j < QMAX; ++j) {
+                if (top == pre[j]) atomicAdd(&hist[j][bin], 1u);
+                else if (pass == 2 && j < NQ && top > pre[j]) mn[j] = min(mn[j], k);
+            })
+        if (pass == 2) {
+#pragma unroll
+            for (int j = 0; j < QMAX; ++j) {
+                unsigned m = mn[j];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, off, 64));
+                if ((tid & 63) == 0 && m != 0xFFFFFFFFu) atomicMin(&sh_min[j], m);
+            }
+        }
+        __syncthreads();
+        for (int j = 0; j < NQ; ++j) {
+            const unsigned hv = hist[j][tid];
+            const unsigned incl = block_scan_incl<QT3>(hv, wtot), excl = incl - hv;
+            const unsigned kk0 = sh_k[j];
+            __syncthreads();                               // everyone has read sh_k[j] before it is rewritten
+            if (kk0 >= excl && kk0 < incl) {
+                sh_prefix[j] = (pre[j] << 10) | (unsigned)tid;
+                sh_k[j] = kk0 - excl;
+            }
+            __syncthreads();
+            if (pass == 2) {
+                // the next non-empty bin above the selected one (the partner when the selected key is not repeated)
+                const unsigned sel = sh_prefix[j] & (QB1 - 1);
+                if (hv != 0 && (unsigned)tid > sel) atomicMin(&sh_next[j], (unsigned)tid);
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < NQ) {
+        const int j = tid;
+        const unsigned n = sh_n;
+        const float rank = a.q[j] * (float)(n - 1);
+        const float lo_f = floorf(rank), w = rank - lo_f;
+        const unsigned key_lo = sh_prefix[j];
+        const float v_lo = key2f(key_lo);
+        float v_hi = v_lo;
+        if (w != 0.f) {
+            const unsigned mult = hist[j][key_lo & (QB1 - 1)];
+            if (sh_k[j] + 1 >= mult) {                     // the element of rank lo + 1 is a larger key
+                if (sh_next[j] != 0xFFFFFFFFu) v_hi = key2f((key_lo & ~(unsigned)(QB1 - 1)) | sh_next[j]);
+                else if (sh_min[j] != 0xFFFFFFFFu) v_hi = key2f(sh_min[j]);
+            }
+        }
+        const float d = v_hi - v_lo;                         // at::lerp: w < 0.5 ? a + w*(b-a) : b - (b-a)*(1-w)
+        a.out[(int64_t)j * a.R + r] = (w < 0.5f) ? v_lo + w * d : v_hi - d * (1.f - w);
+    }
+#undef CP2_Q_FOREACH
+}
+
 static int quant_check(const QuantArgs& a) {
     if (!a.x || !a.q || !a.out) return CP2_ERR_NULL;
     if (a.R <= 0 || a.N <= 0 || a.NQ <= 0) return CP2_ERR_SHAPE;
@@ -520,6 +686,23 @@ CP2_API int64_t cp2_quantiles_workspace_bytes(int njobs, const int* R, const int
 }
 
 static int quant_launch(QuantJobs& jobs, int njobs, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+    bool small = true;
+    for (int j = 0; j < njobs; ++j) small = small && jobs.job[j].N <= QROW_MAX;
+    if (small) {                                           // one launch, one workgroup per row, no workspace
+        size_t lds = 0;
+        int rows = 0;
+        for (int j = 0; j < njobs; ++j) {
+            int rc = quant_check(jobs.job[j]);
+            if (rc) return rc;
+            const size_t l = jobs.job[j].want >= 0 ? 2 * (size_t)jobs.job[j].P * sizeof(float) : 0;
+            if (l > lds) lds = l;
+            jobs.first_row[j] = rows;
+            rows += jobs.job[j].R;
+        }
+        for (int j = njobs; j <= QJOBS; ++j) jobs.first_row[j] = rows;
+        CP2_LAUNCH_PROFILED(quantiles_row_kernel, dim3(rows), dim3(QT3), lds, stream, jobs);
+        return cp2_launch_status();
+    }
     if (!workspace) return CP2_ERR_NULL;
     if (!cp2_aligned16(workspace)) return CP2_ERR_ALIGN;
     int rows = 0, chunks = 0;

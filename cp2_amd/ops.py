@@ -531,6 +531,7 @@ def _quartile_tensor(device) -> torch.Tensor:
 
 
 _QUANT_WS = {}
+QUANTILES_ROW_MAX = 131072     # CP2_QUANTILES_ROW_MAX
 
 
 def _quant_workspace(dev, R, N, NQ):
@@ -577,14 +578,16 @@ def masked_quantiles_multi(jobs, q: Optional[torch.Tensor] = None):
             raise _lib.Cp2LibraryError("masked_quantiles: x must be a float32 GPU tensor")
     ma = [_opt(j.get("mask_a"), "mask_a", torch.float32) for j in jobs]
     mb = [_opt(j.get("mask_b"), "mask_b", torch.float32) for j in jobs]
-    ws = _quant_workspace(dev, [j["R"] for j in jobs], [j["N"] for j in jobs], q.numel())
+    # rows of at most QUANTILES_ROW_MAX elements: one launch, no workspace; longer rows: the chunked three-launch path
+    ws = None if all(j["N"] <= QUANTILES_ROW_MAX for j in jobs) else \
+        _quant_workspace(dev, [j["R"] for j in jobs], [j["N"] for j in jobs], q.numel())
     _profile("quantiles")
     rc = lib.cp2_masked_quantiles_multi(
         n, P_(*[j["x"].data_ptr() for j in jobs]), I64(*[j["stride_row"] for j in jobs]), I64(*[j["stride_elem"] for j in jobs]),
         I32(*[j["R"] for j in jobs]), I32(*[j["N"] for j in jobs]), P_(*ma), P_(*mb),
         I32(*[(j["mask_a"].shape[1] if j.get("mask_a") is not None else 0) for j in jobs]),
         I32(*[j.get("want", -1) for j in jobs]), _dev(q, "q", torch.float32), q.numel(), P_(*[o.data_ptr() for o in outs]),
-        ws.data_ptr(), ws.numel() * 4, _stream())
+        None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel() * 4, _stream())
     _lib.check(rc, "cp2_masked_quantiles_multi")
     return outs
 

@@ -197,8 +197,11 @@ int cp2_masked_quantiles(const float* x, int64_t stride_row, int64_t stride_elem
 /* Up to 4 such problems in one call of three launches (rows cut into 8192-element chunks: first-level histogram,
  * candidate compaction, per-row select; NQ <= 4 quantiles q shared by all jobs).  Every argument of
  * cp2_masked_quantiles becomes a HOST array of njobs entries (device pointers inside).
+ * When every job has N <= CP2_QUANTILES_ROW_MAX the call is ONE launch (one workgroup per row through all three
+ * levels) and needs no workspace (NULL, 0).  Otherwise:
  * workspace: device memory of cp2_quantiles_workspace_bytes(njobs, R, N, NQ) bytes, 16-byte aligned, ZERO before the
  * first call; every call leaves it zero again, so the same buffer serves every later call with the SAME (R, N, NQ). */
+#define CP2_QUANTILES_ROW_MAX 131072
 int64_t cp2_quantiles_workspace_bytes(int njobs, const int* R, const int* N, int NQ);
 int cp2_masked_quantiles_multi(int njobs, const float* const* x, const int64_t* stride_row, const int64_t* stride_elem,
                                const int* R, const int* N, const float* const* mask_a, const float* const* mask_b,

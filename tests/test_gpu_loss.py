@@ -254,7 +254,9 @@ def test_masked_quantiles_bit_exact_vs_torch():
             assert torch.equal(got_t.cpu(), want), (R, N, "strided")
     # chunked rows: many chunks per row, all-equal rows, a narrow band (every element in one first-level bin: the
     # candidate lists overflow and the select re-reads the row), +-inf, and a workspace re-used by consecutive calls
-    for R, N, kind in ((2, 3_000_000, "normal"), (3, 70_001, "const"), (2, 200_003, "band"), (2, 50_000, "inf")):
+    # (rows above 131072 elements take the chunked three-launch path, the others the one-launch row kernel)
+    for R, N, kind in ((2, 3_000_000, "normal"), (3, 270_001, "const"), (3, 70_001, "const"), (2, 200_003, "band"),
+                       (2, 100_000, "band"), (2, 150_000, "inf"), (2, 50_000, "inf")):
         x = torch.randn(R, N, generator=gen) * 0.09
         if kind == "const":
             x[:] = -0.25
@@ -271,7 +273,7 @@ def test_masked_quantiles_bit_exact_vs_torch():
             got = ops.masked_quantiles(xd, N, 1, R, N, q=qs.to(DEV))
             assert np.array_equal(got.cpu().numpy(), want.numpy(), equal_nan=True), (R, N, kind)
     # masked form against the oracle's dense statistics
-    for B, P in ((2, 260), (2, 130)):                           # P % 4 == 0 and != 0, several chunks per row
+    for B, P in ((2, 420), (2, 390), (2, 260), (2, 130)):       # P % 4 == 0 and != 0; chunked (P*P > 131072) and row kernel
         logits = torch.randn(B, P, P, generator=gen) * 0.1
         ma = (torch.rand(B, P, generator=gen) > 0.4).float()
         mb = (torch.rand(B, P, generator=gen) > 0.5).float()

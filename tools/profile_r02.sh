@@ -37,6 +37,13 @@ out["correction"] = "gfx950: FETCH_SIZE counts 128-B requests at 64 B -> x2 (MI3
 out["source"] = "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on tools/bench_instance.py, launches 6-105 / 111-210"
 print(json.dumps(out, indent=1))
 PY
+# 5. quantile statistics: the step's shapes (one-launch row kernel) and BASELINE config 4's shapes (chunked three-launch path)
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d /tmp/p6 -o q --output-format csv -- python3 tools/bench_quantiles.py > $O/r02_quantiles.log 2>&1 || exit 1
+python3 tools/kstats.py /tmp/p6/q_kernel_trace.csv quantile > $O/r02_quantiles_by_shape.txt
+# 6. supervised CutPaste / mirror path: composition and loss kernels at 10 x 512 x 512
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d /tmp/p7 -o m --output-format csv -- python3 tools/bench_mirror.py > $O/r02_mirror.log 2>&1 || exit 1
+python3 tools/kstats.py /tmp/p7/m_kernel_trace.csv cutpaste mirror_loss > $O/r02_mirror_kernels.txt
+cat $O/r02_mirror.log | grep classes >> $O/r02_mirror_kernels.txt
 cp /tmp/p4/f_counter_collection.csv $O/r02_rowkey_small_pmc_fetch_size.csv
 cp /tmp/p5/w_counter_collection.csv $O/r02_rowkey_small_pmc_write_size.csv
 ls -la $O
