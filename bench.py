@@ -107,6 +107,8 @@ def main():
     from cp2_amd import builder, ops, synthetic
     from cp2_amd.encoder import FusedBatchNorm2d
     FusedBatchNorm2d.fused = args.fused_bn == "on"
+    from cp2_amd.encoder import StemMaxPool
+    StemMaxPool.fused = args.fused_bn == "on" and os.environ.get("CP2_STEM_POOL", "1") == "1"   # same encoder fast path (env: A/B)
     from cp2_amd.encoder import Conv2d
     Conv2d.gemm_1x1 = args.gemm_1x1 == "on"
     Conv2d.cpp_nodes = args.cpp_nodes == "on"

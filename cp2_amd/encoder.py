@@ -81,6 +81,39 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
         super()._save_to_state_dict(destination, prefix, keep_vars)
 
 
+class _MaxPool3s2Fn(torch.autograd.Function):
+    """MaxPool2d(3, 2, 1) of the stem on channels-last bf16 activations by csrc/pool.hip (one byte of argmax per output
+    element, gather backward): 13 + 20 us instead of ATen's 35 + 85 us at 32 x 64 x 112 x 112."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y, idx = _bn_ops.maxpool3s2_fwd(x)
+        ctx.save_for_backward(idx)
+        ctx.xshape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        if dy.dtype != torch.bfloat16 or not dy.is_contiguous(memory_format=torch.channels_last):
+            dy = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        return _bn_ops.maxpool3s2_bwd(dy, idx, ctx.xshape)
+
+
+class StemMaxPool(nn.MaxPool2d):
+    """nn.MaxPool2d(3, stride=2, padding=1) (no parameters, same module name in the tree) with the HIP fast path."""
+
+    fused = True
+
+    def forward(self, x):
+        if (StemMaxPool.fused and self.kernel_size == 3 and self.stride == 2 and self.padding == 1 and self.dilation == 1
+                and not self.ceil_mode and not self.return_indices and _bn_ops.maxpool3s2_supported(x)):
+            if torch.is_grad_enabled() and x.requires_grad:
+                return _MaxPool3s2Fn.apply(x)
+            return _bn_ops.maxpool3s2_fwd(x)[0]
+        return super().forward(x)
+
+
 class _ShadowWeightFn(torch.autograd.Function):
     """bf16 image of an fp32 weight as seen by autograd: forward hands out the image (no cast kernel), backward
     returns the gradient in fp32 to the master weight -- what autocast's own cast node does."""
@@ -290,7 +323,7 @@ class ResNet(nn.Module):
         self.conv1 = Conv2d(in_channels, stem_channels, 7, stride=2, padding=3, bias=False)
         self.bn1 = FusedBatchNorm2d(stem_channels)
         self.relu = nn.ReLU(inplace=True)
-        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        self.maxpool = StemMaxPool(3, stride=2, padding=1)
         inplanes = stem_channels
         self.res_layers = []
         for i, nb in enumerate(blocks[:num_stages]):

@@ -677,6 +677,33 @@ def wgrad1x1(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     return dw
 
 
+# ---------------------------------------------------------------- encoder fast path: stem max-pool
+def maxpool3s2_supported(x: torch.Tensor) -> bool:
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] % 8 == 0
+            and x.is_contiguous(memory_format=torch.channels_last))
+
+
+def maxpool3s2_fwd(x: torch.Tensor):
+    """MaxPool2d(3, 2, 1) of a channels-last bf16 activation -> (y channels-last, idx uint8 position codes)."""
+    N, C, H, W = x.shape
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((N, C, OH, OW), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    idx = torch.empty(N * OH * OW * C, dtype=torch.uint8, device=x.device)
+    rc = _lib.load().cp2_maxpool3s2_fwd(x.data_ptr(), y.data_ptr(), idx.data_ptr(), N, H, W, C, _stream())
+    if rc:
+        _lib.check(rc, "cp2_maxpool3s2_fwd")
+    return y, idx
+
+
+def maxpool3s2_bwd(dy: torch.Tensor, idx: torch.Tensor, shape) -> torch.Tensor:
+    N, C, H, W = shape
+    dx = torch.empty((N, C, H, W), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+    rc = _lib.load().cp2_maxpool3s2_bwd(dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), N, H, W, C, _stream())
+    if rc:
+        _lib.check(rc, "cp2_maxpool3s2_bwd")
+    return dx
+
+
 # ---------------------------------------------------------------- f4: supervised CutPaste / mirror pre-training
 CUTPASTE_PARAMS = 20      # CP2_CUTPASTE_PARAMS
 MIRROR_MAX_CLASSES = 8    # CP2_MIRROR_MAX_CLASSES

@@ -265,6 +265,14 @@ int cp2_bn_bwd(const void* x, const void* dy, const void* y, const float* weight
 int cp2_wgrad1x1_num_splits(int M, int CO, int CI);
 int cp2_wgrad1x1(const void* dy, const void* x, float* dw, float* part, int M, int CO, int CI, void* stream);
 
+/* ---- encoder fast path (not a reference call site): the ResNet stem's MaxPool2d(3, stride 2, padding 1) ----------
+ * (mmseg_/models/backbones/resnet.py:413) for channels-last bf16 activations: x [N,H,W,C], y [N,OH,OW,C] with
+ * OH = (H - 1) / 2 + 1 (same for W), C % 8 == 0; idx: one byte per output element = position 0..8 of the maximum in
+ * its window (first maximum in row-major order, NaN wins -- torch's rule), N*OH*OW*C bytes, 8-byte aligned.
+ * Backward gathers: dx [N,H,W,C] = sum of dy over the (at most four) windows whose maximum is that pixel. */
+int cp2_maxpool3s2_fwd(const void* x, void* y, void* idx, int N, int H, int W, int C, void* stream);
+int cp2_maxpool3s2_bwd(const void* dy, const void* idx, void* dx, int N, int H, int W, int C, void* stream);
+
 /* ---- supervised CutPaste / "mirror" pre-training ------------------------------------------------
  * cp2_cutpaste replaces the per-sample numpy / Pillow composition of datasets/pretrain_dataset.py:273-352 (cutpaste)
  * and :357-412 (__getitem__: additional patches, ToTensor).  One launch = one patch round for a whole batch:

@@ -126,3 +126,29 @@ def test_cpp_shadow_weight_node():
     g = torch.randn(64, 32, 3, 3, device=DEV).to(torch.bfloat16)            # NCHW-dense gradient for a channels-last weight
     out.backward(g)
     assert w.grad.dtype == torch.float32 and w.grad.stride() == w.stride() and torch.equal(w.grad, g.float())
+
+
+@pytest.mark.parametrize("N,C,H,W", [(4, 64, 112, 112), (2, 16, 37, 53), (1, 8, 5, 4), (3, 64, 56, 57)])
+def test_stem_maxpool_equals_torch(N, C, H, W):
+    """csrc/pool.hip against torch.nn.MaxPool2d(3, 2, 1) on the same channels-last bf16 input: outputs bit-equal
+    (ties between equal bf16 values resolved as torch does: first in window order), input gradients bit-equal."""
+    from cp2_amd.encoder import StemMaxPool
+    torch.manual_seed(N * C + H)
+    x = torch.randn(N, C, H, W, device=DEV).relu().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)   # many ties at 0
+    x[0, :, 0, 0] = float("nan") if H > 5 else 1.0
+    up = torch.randn(N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    pool = StemMaxPool(3, stride=2, padding=1)
+    xa = x.clone().requires_grad_(True)
+    y = pool(xa)
+    y.backward(up)
+    xr = x.clone().requires_grad_(True)
+    yr = torch.nn.functional.max_pool2d(xr, 3, 2, 1)
+    yr.backward(up)
+    assert y.shape == yr.shape and y.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(torch.nan_to_num(y.float(), nan=-7.0), torch.nan_to_num(yr.float(), nan=-7.0))
+    assert torch.equal(xa.grad, xr.grad)
+    with torch.no_grad():
+        assert torch.equal(torch.nan_to_num(pool(x).float(), nan=-7.0), torch.nan_to_num(yr.float(), nan=-7.0))
+    # anything else falls through to PyTorch
+    xf = torch.randn(2, 8, 9, 9, device=DEV)
+    assert torch.equal(pool(xf), torch.nn.functional.max_pool2d(xf, 3, 2, 1))
