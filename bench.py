@@ -112,6 +112,7 @@ def main():
     from cp2_amd.encoder import Conv2d
     Conv2d.gemm_1x1 = args.gemm_1x1 == "on"
     Conv2d.cpp_nodes = args.cpp_nodes == "on"
+    Conv2d.hip_wgrad_kxk = os.environ.get("CP2_WGRAD_KXK", "1") == "1"     # k x k weight gradients by cp2_wgrad_conv (env: A/B vs MIOpen)
     from cp2_amd.config import Config
     from cp2_amd.engine import TrainStep
     from cp2_amd.main import make_optimizer

@@ -30,5 +30,7 @@ def load():
     lib = _lib.load()
     ext.set_wgrad(ctypes.cast(lib.cp2_wgrad1x1, ctypes.c_void_p).value,
                   ctypes.cast(lib.cp2_wgrad1x1_num_splits, ctypes.c_void_p).value)
+    ext.set_wgrad_conv(ctypes.cast(lib.cp2_wgrad_conv, ctypes.c_void_p).value,
+                       ctypes.cast(lib.cp2_wgrad_conv_num_splits, ctypes.c_void_p).value)
     _ext = ext
     return _ext

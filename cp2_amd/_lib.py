@@ -45,6 +45,8 @@ SIGNATURES = {
     "cp2_bf16_image": [_P, _P, c_int64, _P],
     "cp2_wgrad1x1_num_splits": [c_int, c_int, c_int],
     "cp2_wgrad1x1": [_P, _P, _P, _P, c_int, c_int, c_int, _P],
+    "cp2_wgrad_conv_num_splits": [c_int] * 7,
+    "cp2_wgrad_conv": [_P, _P, _P, _P] + [c_int] * 12 + [_P],
     "cp2_bn_num_partials": [c_int, c_int],
     "cp2_bn_fwd": [_P, _P, _P, _P, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P],
     "cp2_bn_bwd": [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, _P],

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void cutpaste_kernel(CutPasteArgs a) {
     const unsigned char* mir = a.src_mirror ? a.src_mirror + (int64_t)mi * HW * 3 : nullptr;
     const int64_t o = (int64_t)y * a.W + x0;
     unsigned char vi[VEC * 3], vm[VEC * 3];
-    if (VEC == 4) {                                  // 12 bytes = three aligned dwords (W % 4 == 0)
+    if constexpr (VEC == 4) {                        // 12 bytes = three aligned dwords (W % 4 == 0)
         const uint32_t* q = reinterpret_cast<const uint32_t*>(img + o * 3);
         uint32_t w3[3] = {q[0], q[1], q[2]};
         __builtin_memcpy(vi, w3, 12);
@@ -178,73 +178,120 @@ __device__ __forceinline__ int class_ce(const float (&x)[ML_CMAX], int lab, floa
     return am;
 }
 
+// Everything one pixel contributes: both class cross entropies, the compare loss, both gradients, both arg-maxes.
 template <int C>
+__device__ __forceinline__ void mirror_pixel(const float (&xs)[ML_CMAX], const float (&xt)[ML_CMAX], int lab, bool two, bool want_grad,
+                                             float temp, float lmbd, float m_cls, float m_cmp, float (&gs)[ML_CMAX],
+                                             float (&gt)[ML_CMAX], int& am_s, int& am_t, float& acc_cls, float& acc_cmp) {
+    // ---- class cross entropy (nn.CrossEntropyLoss over cat(s, t) with cat(masks, masks)), mean over all pixels
+    am_s = class_ce<C>(xs, lab, m_cls, gs, acc_cls);
+    am_t = 0;
+    if (!two) return;
+    am_t = class_ce<C>(xt, lab, m_cls, gt, acc_cls);
+    // ---- compare loss: cross_entropy(softmax(s / T), softmax(t / T)) with probability targets, mean over N*HW
+    float zs[ML_CMAX], zt[ML_CMAX], ps[ML_CMAX], pt[ML_CMAX], u[ML_CMAX];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { zs[c] = xs[c] / temp; zt[c] = xt[c] / temp; }
+    float mx, ls, sum;
+    lse_of<C>(zs, mx, ls);
+    sum = expf(ls);
+#pragma unroll
+    for (int c = 0; c < C; ++c) ps[c] = expf(zs[c] - mx) / sum;
+    lse_of<C>(zt, mx, ls);
+    sum = expf(ls);
+#pragma unroll
+    for (int c = 0; c < C; ++c) pt[c] = expf(zt[c] - mx) / sum;
+    lse_of<C>(ps, mx, ls);
+    float l = 0.f, spt = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) { u[c] = (ps[c] - mx) - ls; l += pt[c] * u[c]; spt += pt[c]; }
+    acc_cmp += -l;
+    if (want_grad) {
+        // d/du = -pt/M;  log_softmax backward: g_ps = g_u - exp(u) * sum(g_u);  softmax backward, then / T
+        float gps[ML_CMAX], gpt[ML_CMAX], dot_s = 0.f, dot_t = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            gps[c] = (-pt[c] + expf(u[c]) * spt) / m_cmp;
+            gpt[c] = -u[c] / m_cmp;
+            dot_s += gps[c] * ps[c];
+            dot_t += gpt[c] * pt[c];
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            gs[c] += lmbd * (ps[c] * (gps[c] - dot_s) / temp);
+            gt[c] += lmbd * (pt[c] * (gpt[c] - dot_t) / temp);
+        }
+    }
+}
+
+// VEC = 4: a thread owns four consecutive pixels (16-byte loads and stores per channel plane; HW % 4 == 0, aligned
+// planes); VEC = 1: one pixel per thread.
+template <int C, int VEC>
 __global__ __launch_bounds__(ML_T) void mirror_loss_kernel(MirrorLossArgs a) {
     __shared__ unsigned int conf[ML_CMAX * ML_CMAX];
     __shared__ double red[2][ML_T / 64];
     const int n = blockIdx.y, tid = threadIdx.x;
     if (a.confusion) { for (int i = tid; i < C * C; i += ML_T) conf[i] = 0; __syncthreads(); }
-    const bool two = a.t != nullptr;
+    const bool two = a.t != nullptr, want_grad = a.grad_s != nullptr;
     const float m_cls = (float)((two ? 2.0 : 1.0) * (double)a.N * (double)a.HW), m_cmp = (float)((double)a.N * (double)a.HW);
     float acc_cls = 0.f, acc_cmp = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * ML_T + tid; i < a.HW; i += (int64_t)gridDim.x * ML_T) {
+    for (int64_t i = ((int64_t)blockIdx.x * ML_T + tid) * VEC; i < a.HW; i += (int64_t)gridDim.x * ML_T * VEC) {
         const int64_t base = (int64_t)n * C * a.HW + i;
-        const int64_t lab64 = a.masks[(int64_t)n * a.HW + i];
-        const int lab = (int)lab64;
-        float xs[ML_CMAX], xt[ML_CMAX], gs[ML_CMAX], gt[ML_CMAX];
+        float xs[VEC][ML_CMAX], xt[VEC][ML_CMAX], gs[VEC][ML_CMAX], gt[VEC][ML_CMAX];
+        int lab[VEC], am_s[VEC], am_t[VEC];
+        if (VEC == 4) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) { xs[c] = a.s[base + c * a.HW]; xt[c] = two ? a.t[base + c * a.HW] : 0.f; }
-        // ---- class cross entropy (nn.CrossEntropyLoss over cat(s, t) with cat(masks, masks)), mean over all pixels
-        const int am_s = class_ce<C>(xs, lab, m_cls, gs, acc_cls);
-        if (a.argmax) a.argmax[(int64_t)n * a.HW + i] = am_s;
-        if (a.confusion && lab >= 0 && lab < C) atomicAdd(&conf[lab * C + am_s], 1u);
-        if (two) {
-            const int am_t = class_ce<C>(xt, lab, m_cls, gt, acc_cls);
-            if (a.argmax) a.argmax[((int64_t)(a.N + n)) * a.HW + i] = am_t;
-            if (a.confusion && lab >= 0 && lab < C) atomicAdd(&conf[lab * C + am_t], 1u);
+            for (int c = 0; c < C; ++c) {
+                const float4 v = *reinterpret_cast<const float4*>(a.s + base + c * a.HW);
+                xs[0][c] = v.x; xs[1 % VEC][c] = v.y; xs[2 % VEC][c] = v.z; xs[3 % VEC][c] = v.w;
+                float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (two) w = *reinterpret_cast<const float4*>(a.t + base + c * a.HW);
+                xt[0][c] = w.x; xt[1 % VEC][c] = w.y; xt[2 % VEC][c] = w.z; xt[3 % VEC][c] = w.w;
+            }
+            const longlong2* mp = reinterpret_cast<const longlong2*>(a.masks + (int64_t)n * a.HW + i);
+            const longlong2 m0 = mp[0], m1 = mp[1];
+            lab[0] = (int)m0.x; lab[1 % VEC] = (int)m0.y; lab[2 % VEC] = (int)m1.x; lab[3 % VEC] = (int)m1.y;
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c) { xs[0][c] = a.s[base + c * a.HW]; xt[0][c] = two ? a.t[base + c * a.HW] : 0.f; }
+            lab[0] = (int)a.masks[(int64_t)n * a.HW + i];
         }
-        // ---- compare loss: cross_entropy(softmax(s / T), softmax(t / T)) with probability targets, mean over N*HW
-        if (two) {
-            float zs[ML_CMAX], zt[ML_CMAX], ps[ML_CMAX], pt[ML_CMAX], u[ML_CMAX];
 #pragma unroll
-            for (int c = 0; c < C; ++c) { zs[c] = xs[c] / a.temp; zt[c] = xt[c] / a.temp; }
-            float mx, ls, sum;
-            lse_of<C>(zs, mx, ls);
-            sum = expf(ls);
-#pragma unroll
-            for (int c = 0; c < C; ++c) ps[c] = expf(zs[c] - mx) / sum;
-            lse_of<C>(zt, mx, ls);
-            sum = expf(ls);
-#pragma unroll
-            for (int c = 0; c < C; ++c) pt[c] = expf(zt[c] - mx) / sum;
-            lse_of<C>(ps, mx, ls);
-            float l = 0.f, spt = 0.f;
-#pragma unroll
-            for (int c = 0; c < C; ++c) { u[c] = (ps[c] - mx) - ls; l += pt[c] * u[c]; spt += pt[c]; }
-            acc_cmp += -l;
-            if (a.grad_s) {
-                // d/du = -pt/M;  log_softmax backward: g_ps = g_u - exp(u) * sum(g_u);  softmax backward, then / T
-                float gps[ML_CMAX], gpt[ML_CMAX], dot_s = 0.f, dot_t = 0.f;
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    gps[c] = (-pt[c] + expf(u[c]) * spt) / m_cmp;
-                    gpt[c] = -u[c] / m_cmp;
-                    dot_s += gps[c] * ps[c];
-                    dot_t += gpt[c] * pt[c];
-                }
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    gs[c] += a.lmbd * (ps[c] * (gps[c] - dot_s) / a.temp);
-                    gt[c] += a.lmbd * (pt[c] * (gpt[c] - dot_t) / a.temp);
-                }
+        for (int v = 0; v < VEC; ++v) {
+            mirror_pixel<C>(xs[v], xt[v], lab[v], two, want_grad, a.temp, a.lmbd, m_cls, m_cmp, gs[v], gt[v], am_s[v], am_t[v], acc_cls, acc_cmp);
+            if (a.confusion && lab[v] >= 0 && lab[v] < C) {
+                atomicAdd(&conf[lab[v] * C + am_s[v]], 1u);
+                if (two) atomicAdd(&conf[lab[v] * C + am_t[v]], 1u);
             }
         }
-        if (a.grad_s) {
+        if (VEC == 4) {
+            if (a.argmax) {
+                longlong2* o = reinterpret_cast<longlong2*>(a.argmax + (int64_t)n * a.HW + i);
+                o[0] = longlong2{am_s[0], am_s[1 % VEC]}; o[1] = longlong2{am_s[2 % VEC], am_s[3 % VEC]};
+                if (two) {
+                    longlong2* ot = reinterpret_cast<longlong2*>(a.argmax + ((int64_t)(a.N + n)) * a.HW + i);
+                    ot[0] = longlong2{am_t[0], am_t[1 % VEC]}; ot[1] = longlong2{am_t[2 % VEC], am_t[3 % VEC]};
+                }
+            }
+            if (want_grad) {
 #pragma unroll
-            for (int c = 0; c < C; ++c) { a.grad_s[base + c * a.HW] = gs[c]; if (two) a.grad_t[base + c * a.HW] = gt[c]; }
+                for (int c = 0; c < C; ++c) {
+                    *reinterpret_cast<float4*>(a.grad_s + base + c * a.HW) = make_float4(gs[0][c], gs[1 % VEC][c], gs[2 % VEC][c], gs[3 % VEC][c]);
+                    if (two) *reinterpret_cast<float4*>(a.grad_t + base + c * a.HW) = make_float4(gt[0][c], gt[1 % VEC][c], gt[2 % VEC][c], gt[3 % VEC][c]);
+                }
+            }
+        } else {
+            if (a.argmax) {
+                a.argmax[(int64_t)n * a.HW + i] = am_s[0];
+                if (two) a.argmax[((int64_t)(a.N + n)) * a.HW + i] = am_t[0];
+            }
+            if (want_grad) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) { a.grad_s[base + c * a.HW] = gs[0][c]; if (two) a.grad_t[base + c * a.HW] = gt[0][c]; }
+            }
         }
     }
-    // per-workgroup partial sums in a fixed order (deterministic); the finalize kernel adds them in index order
+    // per-workgroup partial sums in a fixed order (deterministic); the finalize kernel adds them in a fixed order too
     double dc = (double)wave_sum(acc_cls), dm = (double)wave_sum(acc_cmp);
     if ((tid & 63) == 0) { red[0][tid >> 6] = dc; red[1][tid >> 6] = dm; }
     __syncthreads();
@@ -260,12 +307,18 @@ __global__ __launch_bounds__(ML_T) void mirror_loss_kernel(MirrorLossArgs a) {
     }
 }
 
-// out[0] = loss, out[1] = class_loss, out[2] = compare_loss (fp32, as the reference logs them)
-__global__ void mirror_loss_finalize_kernel(const double* __restrict__ partial, int nparts, double m_cls, double m_cmp, float lmbd,
-                                            int two, float* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// out[0] = loss, out[1] = class_loss, out[2] = compare_loss (fp32, as the reference logs them).  One workgroup: thread
+// t adds partials t, t + 256, ... in that order, thread 0 adds the 256 lane sums in lane order -- a fixed tree.
+__global__ __launch_bounds__(256) void mirror_loss_finalize_kernel(const double* __restrict__ partial, int nparts, double m_cls,
+                                                                   double m_cmp, float lmbd, int two, float* __restrict__ out) {
+    __shared__ double r0[256], r1[256];
     double c0 = 0, c1 = 0;
-    for (int i = 0; i < nparts; ++i) { c0 += partial[2 * i]; c1 += partial[2 * i + 1]; }
+    for (int i = threadIdx.x; i < nparts; i += 256) { c0 += partial[2 * i]; c1 += partial[2 * i + 1]; }
+    r0[threadIdx.x] = c0; r1[threadIdx.x] = c1;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    c0 = 0; c1 = 0;
+    for (int i = 0; i < 256; ++i) { c0 += r0[i]; c1 += r1[i]; }
     const float cls = (float)(c0 / m_cls), cmp = two ? (float)(c1 / m_cmp) : 0.f;
     out[0] = cls + lmbd * cmp;
     out[1] = cls;
@@ -294,16 +347,27 @@ CP2_API int cp2_mirror_loss(const float* s_logits, const float* t_logits, const 
                      reinterpret_cast<unsigned long long*>(confusion), partial, N, C, HW};
     hipStream_t st = cp2_stream(stream);
     const dim3 grid(gx, N), block(ML_T);
+    // measured at 10 x 512 x 512 (rocprofv3): the 4-pixel form is 8-12 % SLOWER than one pixel per thread (58 vs 54 us at
+    // C = 2, 80 vs 72 at C = 3) -- the kernel is bound by its ~20 expf / logf per pixel, not by the shape of its memory
+    // accesses, and the wider form only adds register pressure; it stays compiled for reference and is not selected
+    const bool vec = false && C <= 4 && HW % 4 == 0 && cp2_aligned16(s_logits) && (!t_logits || cp2_aligned16(t_logits)) && cp2_aligned16(masks) &&
+                     (!grad_s || cp2_aligned16(grad_s)) && (!grad_t || cp2_aligned16(grad_t)) && (!argmax || cp2_aligned16(argmax));
     switch (C) {
-#define CP2_ML_CASE(CC) case CC: CP2_LAUNCH_PROFILED(mirror_loss_kernel<CC>, grid, block, 0, st, a); break;
-        CP2_ML_CASE(2) CP2_ML_CASE(3) CP2_ML_CASE(4) CP2_ML_CASE(5) CP2_ML_CASE(6) CP2_ML_CASE(7) CP2_ML_CASE(8)
-#undef CP2_ML_CASE
+#define CP2_ML_LAUNCH(CC, VV) CP2_LAUNCH_PROFILED((mirror_loss_kernel<CC, VV>), grid, block, 0, st, a)
+        case 2: if (vec) CP2_ML_LAUNCH(2, 4); else CP2_ML_LAUNCH(2, 1); break;
+        case 3: if (vec) CP2_ML_LAUNCH(3, 4); else CP2_ML_LAUNCH(3, 1); break;
+        case 4: if (vec) CP2_ML_LAUNCH(4, 4); else CP2_ML_LAUNCH(4, 1); break;
+        case 5: CP2_ML_LAUNCH(5, 1); break;
+        case 6: CP2_ML_LAUNCH(6, 1); break;
+        case 7: CP2_ML_LAUNCH(7, 1); break;
+        case 8: CP2_ML_LAUNCH(8, 1); break;
+#undef CP2_ML_LAUNCH
         default: return CP2_ERR_UNSUPPORTED;
     }
     int rc = cp2_launch_status();
     if (rc) return rc;
     const double two = t_logits ? 2.0 : 1.0;
-    hipLaunchKernelGGL(mirror_loss_finalize_kernel, dim3(1), dim3(64), 0, st, partial, nparts, two * (double)N * (double)HW,
+    hipLaunchKernelGGL(mirror_loss_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nparts, two * (double)N * (double)HW,
                        (double)N * (double)HW, lmbd_compare_loss, t_logits ? 1 : 0, out3);
     return cp2_launch_status();
 }

@@ -42,17 +42,39 @@ __device__ __forceinline__ int wg_xcd_item(int id, int n_items) {
     return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + j;
 }
 
-template <int F>   // F x F MFMA tiles per wave; workgroup tile = 64F x 64F channels, 4 waves as 2 x 2
+// k x k convolution (CONV): the same product per filter tap, dW[co][kh][kw][ci] = sum_m dY[m][co] * X[row(m, kh, kw)][ci] with
+// m = (n, oh, ow) an OUTPUT pixel and row(m, kh, kw) the input pixel (oh*stride - pad + kh*dil, ow*stride - pad + kw*dil) of
+// image n, or a zero row outside the image.  A workgroup owns (co tile, tap, ci tile); its threads track (n, oh, ow) of
+// their rows incrementally from stage to stage (one division when the workgroup starts).
+struct WgConv { int H, W, OH, OW, KW, taps, stride, pad, dil; };
+
+template <int F, bool CONV>   // F x F MFMA tiles per wave; workgroup tile = 64F x 64F channels, 4 waves as 2 x 2
 __global__ __launch_bounds__(256) void wgrad1x1_kernel(const unsigned short* __restrict__ dy,
                                                        const unsigned short* __restrict__ x, float* __restrict__ part,
-                                                       int M, int CO, int CI, int rows_per_split, int tiles_ci, int tiles) {
+                                                       int M, int CO, int CI, int rows_per_split, int tiles_ci, int tiles, WgConv cv) {
     constexpr int T = 64 * F, PITCH = T + 8, CPR = T / 8;            // channels per tile edge, LDS row pitch, 16-B chunks per row
     __shared__ __attribute__((aligned(16))) unsigned short lds[2][2][WG_KM * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wy = wid >> 1, wx = wid & 1;
     const int r = lane & 31, h = lane >> 5;
     const int item = wg_xcd_item(blockIdx.x, gridDim.x), split = item / tiles, tile = item % tiles;
-    const int co0 = (tile / tiles_ci) * T, ci0 = (tile % tiles_ci) * T;
+    const int taps = CONV ? cv.taps : 1;
+    const int tap = CONV ? (tile / tiles_ci) % taps : 0;
+    const int co0 = (tile / (tiles_ci * taps)) * T, ci0 = (tile % tiles_ci) * T;
     const int m_begin = split * rows_per_split, m_end = min(M, m_begin + rows_per_split);
+    // CONV: (image, output row, output column) of this thread's F rows of the current stage, and the tap's input offset
+    int pn[F], poh[F], pow_[F];
+    const int dh = CONV ? (tap / cv.KW) * cv.dil - cv.pad : 0, dw_ = CONV ? (tap % cv.KW) * cv.dil - cv.pad : 0;
+    if (CONV) {
+#pragma unroll
+        for (int j = 0; j < F; ++j) {
+            const int m = m_begin + (tid + j * 256) / CPR;
+            const int per = cv.OH * cv.OW;
+            pn[j] = m / per;
+            const int rem = m - pn[j] * per;
+            poh[j] = rem / cv.OW;
+            pow_[j] = rem - poh[j] * cv.OW;
+        }
+    }
     wg_f32x16 acc[F][F];
 #pragma unroll
     for (int a = 0; a < F; ++a)
@@ -65,7 +87,17 @@ __global__ __launch_bounds__(256) void wgrad1x1_kernel(const unsigned short* __r
             const int c = tid + j * 256, row = c / CPR, col = (c % CPR) * 8, m = m0 + row;
             const bool ok = m < m_end;
             ra[j] = ok ? *reinterpret_cast<const wg_u32x4*>(dy + (int64_t)m * CO + co0 + col) : (wg_u32x4){0, 0, 0, 0};
-            rb[j] = ok ? *reinterpret_cast<const wg_u32x4*>(x + (int64_t)m * CI + ci0 + col) : (wg_u32x4){0, 0, 0, 0};
+            if (CONV) {
+                const int ih = poh[j] * cv.stride + dh, iw = pow_[j] * cv.stride + dw_;
+                const bool in = ok && ih >= 0 && ih < cv.H && iw >= 0 && iw < cv.W;
+                rb[j] = in ? *reinterpret_cast<const wg_u32x4*>(x + (((int64_t)pn[j] * cv.H + ih) * cv.W + iw) * CI + ci0 + col)
+                           : (wg_u32x4){0, 0, 0, 0};
+                pow_[j] += WG_KM;                              // the same thread's row of the next stage: m + WG_KM
+                while (pow_[j] >= cv.OW) { pow_[j] -= cv.OW; ++poh[j]; }
+                while (poh[j] >= cv.OH) { poh[j] -= cv.OH; ++pn[j]; }
+            } else {
+                rb[j] = ok ? *reinterpret_cast<const wg_u32x4*>(x + (int64_t)m * CI + ci0 + col) : (wg_u32x4){0, 0, 0, 0};
+            }
         }
     };
     auto store = [&](int buf) {
@@ -98,14 +130,14 @@ __global__ __launch_bounds__(256) void wgrad1x1_kernel(const unsigned short* __r
         __syncthreads();
         buf ^= 1;
     }
-    float* out = part + (int64_t)split * CO * CI;
+    float* out = part + (int64_t)split * CO * CI * taps;
 #pragma unroll
     for (int a = 0; a < F; ++a)
 #pragma unroll
         for (int b = 0; b < F; ++b)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg)
-                out[(int64_t)(co0 + wy * 32 * F + a * 32 + wg_rho(reg, h)) * CI + ci0 + wx * 32 * F + b * 32 + r] = acc[a][b][reg];
+                out[((int64_t)(co0 + wy * 32 * F + a * 32 + wg_rho(reg, h)) * taps + tap) * CI + ci0 + wx * 32 * F + b * 32 + r] = acc[a][b][reg];
 }
 
 // dw = sum over splits, in split order per element: 16 float4 columns x 16 split lanes per workgroup, 8 loads in flight
@@ -138,19 +170,19 @@ __global__ __launch_bounds__(256) void wgrad_sum_kernel(const float* __restrict_
     }
 }
 
-static int wgrad_geom(int M, int CO, int CI, int* F, int* S, int* rows) {
-    if (M <= 0 || CO <= 0 || CI <= 0) return CP2_ERR_SHAPE;
+static int wgrad_geom(int M, int CO, int CI, int* F, int* S, int* rows, int taps = 1) {
+    if (M <= 0 || CO <= 0 || CI <= 0 || taps <= 0) return CP2_ERR_SHAPE;
     if (CO % 64 != 0 || CI % 64 != 0) return CP2_ERR_UNSUPPORTED;
     *F = (CO % 128 == 0 && CI % 128 == 0) ? 2 : 1;
     const int T = 64 * *F;
-    const int64_t tiles = (int64_t)(CO / T) * (CI / T);
+    const int64_t tiles = (int64_t)(CO / T) * (CI / T) * taps;
     int64_t s = (512 + tiles - 1) / tiles;                 // two workgroups per CU in all (measured: 512 < 768 < 1024 < 1536
                                                            // in total time over the ResNet-50 shapes, 398 / 423 / 433 / 448 us)
     const int64_t max_s = (M + 2 * WG_KM - 1) / (2 * WG_KM);
     if (s > max_s) s = max_s;
     // partial tiles are written and read once more: keep that within 3x the operand traffic (measured: parallelism
     // matters more than those bytes -- 512->2048 channels at M = 6272 takes 39 us with 12 splits, 115 us with one)
-    const int64_t cap = ((int64_t)3 * 2 * M * (CO + CI)) / ((int64_t)8 * CO * CI);
+    const int64_t cap = ((int64_t)3 * 2 * M * (CO + CI) * taps) / ((int64_t)8 * CO * CI * taps);
     if (s > cap) s = cap;
     if (s < 1) s = 1;
     if (s < 1) s = 1;
@@ -181,11 +213,56 @@ CP2_API int cp2_wgrad1x1(const void* dy, const void* x, float* dw, float* part, 
     const int tiles = (CO / T) * tiles_ci;
     const dim3 grid(tiles * S);
     float* out = S == 1 ? dw : part;
-    if (F == 2) hipLaunchKernelGGL(wgrad1x1_kernel<2>, grid, dim3(256), 0, s, d, xx, out, M, CO, CI, rows, tiles_ci, tiles);
-    else hipLaunchKernelGGL(wgrad1x1_kernel<1>, grid, dim3(256), 0, s, d, xx, out, M, CO, CI, rows, tiles_ci, tiles);
+    const WgConv none{};
+    if (F == 2) hipLaunchKernelGGL((wgrad1x1_kernel<2, false>), grid, dim3(256), 0, s, d, xx, out, M, CO, CI, rows, tiles_ci, tiles, none);
+    else hipLaunchKernelGGL((wgrad1x1_kernel<1, false>), grid, dim3(256), 0, s, d, xx, out, M, CO, CI, rows, tiles_ci, tiles, none);
     int rc2 = cp2_launch_status();
     if (rc2 || S == 1) return rc2;
     const int64_t n4 = (int64_t)CO * CI / 4;
+    hipLaunchKernelGGL(wgrad_sum_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, s, part, dw, S, n4);
+    return cp2_launch_status();
+}
+
+// ---- k x k convolution (3x3 of the ResNet bottlenecks and of the FCN head): dy [N,OH,OW,CO], x [N,H,W,CI] bf16
+// channels-last, dw fp32 [CO][KH][KW][CI] (the memory order of a channels-last weight)
+static int wgrad_conv_check(int N, int H, int W, int OH, int OW, int KH, int KW, int stride, int pad, int dil) {
+    if (N <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0 || dil <= 0) return CP2_ERR_SHAPE;
+    if (KH * KW > 49) return CP2_ERR_UNSUPPORTED;
+    if ((H + 2 * pad - dil * (KH - 1) - 1) / stride + 1 != OH || (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1 != OW) return CP2_ERR_SHAPE;
+    if ((int64_t)N * OH * OW > 0x7fffffff) return CP2_ERR_UNSUPPORTED;
+    return CP2_OK;
+}
+
+CP2_API int cp2_wgrad_conv_num_splits(int N, int OH, int OW, int CO, int CI, int KH, int KW) {
+    if (N <= 0 || OH <= 0 || OW <= 0 || KH <= 0 || KW <= 0) return CP2_ERR_SHAPE;
+    int F, S, rows;
+    const int rc = wgrad_geom(N * OH * OW, CO, CI, &F, &S, &rows, KH * KW);
+    return rc ? rc : S;
+}
+
+CP2_API int cp2_wgrad_conv(const void* dy, const void* x, float* dw, float* part, int N, int H, int W, int OH, int OW, int CO,
+                           int CI, int KH, int KW, int stride, int pad, int dil, void* stream) {
+    if (!dy || !x || !dw || !part) return CP2_ERR_NULL;
+    int rc = wgrad_conv_check(N, H, W, OH, OW, KH, KW, stride, pad, dil);
+    if (rc) return rc;
+    const int M = N * OH * OW, taps = KH * KW;
+    int F, S, rows;
+    rc = wgrad_geom(M, CO, CI, &F, &S, &rows, taps);
+    if (rc) return rc;
+    if (!cp2_aligned16(dy) || !cp2_aligned16(x) || !cp2_aligned16(dw) || !cp2_aligned16(part)) return CP2_ERR_ALIGN;
+    const unsigned short* d = static_cast<const unsigned short*>(dy);
+    const unsigned short* xx = static_cast<const unsigned short*>(x);
+    hipStream_t s = cp2_stream(stream);
+    const int T = 64 * F, tiles_ci = CI / T;
+    const int tiles = (CO / T) * taps * tiles_ci;
+    const dim3 grid(tiles * S);
+    float* out = S == 1 ? dw : part;
+    const WgConv cv{H, W, OH, OW, KW, taps, stride, pad, dil};
+    if (F == 2) hipLaunchKernelGGL((wgrad1x1_kernel<2, true>), grid, dim3(256), 0, s, d, xx, out, M, CO, CI, rows, tiles_ci, tiles, cv);
+    else hipLaunchKernelGGL((wgrad1x1_kernel<1, true>), grid, dim3(256), 0, s, d, xx, out, M, CO, CI, rows, tiles_ci, tiles, cv);
+    int rc2 = cp2_launch_status();
+    if (rc2 || S == 1) return rc2;
+    const int64_t n4 = (int64_t)CO * CI * taps / 4;
     hipLaunchKernelGGL(wgrad_sum_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, s, part, dw, S, n4);
     return cp2_launch_status();
 }

@@ -19,6 +19,16 @@ typedef int (*wgrad_splits_fn_t)(int, int, int);
 wgrad_fn_t g_wgrad = nullptr;
 wgrad_splits_fn_t g_wgrad_splits = nullptr;
 
+typedef int (*wgrad_conv_fn_t)(const void*, const void*, float*, float*, int, int, int, int, int, int, int, int, int, int, int, int, void*);
+typedef int (*wgrad_conv_splits_fn_t)(int, int, int, int, int, int, int);
+wgrad_conv_fn_t g_wgrad_conv = nullptr;
+wgrad_conv_splits_fn_t g_wgrad_conv_splits = nullptr;
+
+void set_wgrad_conv(int64_t fn, int64_t splits_fn) {
+    g_wgrad_conv = reinterpret_cast<wgrad_conv_fn_t>(fn);
+    g_wgrad_conv_splits = reinterpret_cast<wgrad_conv_splits_fn_t>(splits_fn);
+}
+
 void set_wgrad(int64_t fn, int64_t splits_fn) {
     g_wgrad = reinterpret_cast<wgrad_fn_t>(fn);
     g_wgrad_splits = reinterpret_cast<wgrad_splits_fn_t>(splits_fn);
@@ -116,7 +126,66 @@ struct Conv1x1Fn : public torch::autograd::Function<Conv1x1Fn> {
     }
 };
 
+// k x k convolution (the 3x3 layers): forward and data gradient by MIOpen, weight gradient by cp2_wgrad_conv -- fp32, in the
+// master weight's channels-last strides, deterministic; MIOpen's split-K weight-gradient solvers for these layers run a
+// zero-fill kernel, the atomic-accumulating kernel and a cast kernel, and hand back bf16 that is cast to fp32 once more.
+struct ConvKxKFn : public torch::autograd::Function<ConvKxKFn> {
+    static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& x, const at::Tensor& weight,
+                              const at::Tensor& shadow, const c10::optional<at::Tensor>& bias, int64_t stride, int64_t pad,
+                              int64_t dil) {
+        c10::optional<at::Tensor> b16;
+        if (bias.has_value() && bias->defined()) b16 = bias->to(at::kBFloat16);
+        const at::Tensor y = at::conv2d(x, shadow, b16, {stride, stride}, {pad, pad}, {dil, dil});
+        ctx->save_for_backward({x, shadow});
+        ctx->saved_data["geom"] = std::vector<int64_t>{stride, pad, dil};
+        ctx->saved_data["has_bias"] = b16.has_value();
+        ctx->saved_data["wshape"] = weight.sizes().vec();
+        ctx->saved_data["wstride"] = weight.strides().vec();
+        return y;
+    }
+
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grads) {
+        const auto saved = ctx->get_saved_variables();
+        const at::Tensor& x = saved[0];
+        const at::Tensor& w = saved[1];
+        const auto geom = ctx->saved_data["geom"].toIntVector();
+        const int64_t stride = geom[0], pad = geom[1], dil = geom[2];
+        const int64_t N = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3), co = w.size(0), k = w.size(2);
+        at::Tensor dy = grads[0];
+        if (dy.scalar_type() != at::kBFloat16 || !dy.is_contiguous(at::MemoryFormat::ChannelsLast))
+            dy = dy.to(at::kBFloat16).contiguous(at::MemoryFormat::ChannelsLast);
+        const int64_t OH = dy.size(2), OW = dy.size(3);
+        const bool need_dx = ctx->needs_input_grad(0), need_dw = ctx->needs_input_grad(1);
+        const bool need_db = ctx->saved_data["has_bias"].toBool() && ctx->needs_input_grad(3);
+        at::Tensor dx, dw, db;
+        if (need_dw) {
+            const int S = g_wgrad_conv_splits((int)N, (int)OH, (int)OW, (int)co, (int)C, (int)k, (int)k);
+            TORCH_CHECK(S >= 1, "cp2_wgrad_conv_num_splits failed: ", S);
+            dw = at::empty_strided(ctx->saved_data["wshape"].toIntVector(), ctx->saved_data["wstride"].toIntVector(),
+                                   x.options().dtype(at::kFloat));
+            at::Tensor part = S > 1 ? at::empty({(int64_t)S * dw.numel()}, dw.options()) : dw;
+            const int rc = g_wgrad_conv(dy.data_ptr(), x.data_ptr(), dw.data_ptr<float>(), part.data_ptr<float>(), (int)N, (int)H, (int)W,
+                                        (int)OH, (int)OW, (int)co, (int)C, (int)k, (int)k, (int)stride, (int)pad, (int)dil,
+                                        c10::hip::getCurrentHIPStream().stream());
+            TORCH_CHECK(rc == 0, "cp2_wgrad_conv failed: ", rc);
+        }
+        if (need_db) db = dy.permute({0, 2, 3, 1}).reshape({N, OH * OW, co}).sum(1, false, at::kFloat).sum(0);
+        if (need_dx) {
+            const auto r = at::convolution_backward(dy, x, w, c10::nullopt, {stride, stride}, {pad, pad}, {dil, dil}, false, {0, 0}, 1,
+                                                    {true, false, false});
+            dx = std::get<0>(r);
+        }
+        return {dx, dw, at::Tensor(), db, at::Tensor(), at::Tensor(), at::Tensor()};
+    }
+};
+
 at::Tensor shadow_weight(const at::Tensor& weight, const at::Tensor& shadow) { return ShadowWeightFn::apply(weight, shadow); }
+
+at::Tensor conv_kxk(const at::Tensor& x, const at::Tensor& weight, const at::Tensor& shadow, const c10::optional<at::Tensor>& bias,
+                    int64_t stride, int64_t pad, int64_t dil) {
+    TORCH_CHECK(g_wgrad_conv != nullptr, "set_wgrad_conv has not been called");
+    return ConvKxKFn::apply(x, weight, shadow, bias, stride, pad, dil);
+}
 
 at::Tensor conv1x1(const at::Tensor& x, const at::Tensor& weight, const at::Tensor& shadow, const c10::optional<at::Tensor>& bias,
                    bool mm_fwd, bool mm_dgrad, bool hip_wgrad) {
@@ -127,6 +196,8 @@ at::Tensor conv1x1(const at::Tensor& x, const at::Tensor& weight, const at::Tens
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("set_wgrad", &set_wgrad, "function pointers of cp2_wgrad1x1 / cp2_wgrad1x1_num_splits (libcp2hip.so)");
+    m.def("set_wgrad_conv", &set_wgrad_conv, "function pointers of cp2_wgrad_conv / cp2_wgrad_conv_num_splits (libcp2hip.so)");
+    m.def("conv_kxk", &conv_kxk);
     m.def("shadow_weight", &shadow_weight);
     m.def("conv1x1", &conv1x1);
 }

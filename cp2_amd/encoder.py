@@ -186,6 +186,35 @@ class _Conv1x1Fn(torch.autograd.Function):
         return dx, dw, None, db, None, None
 
 
+class _ConvKxKFn(torch.autograd.Function):
+    """Python twin of the C++ node conv_kxk (csrc_torch/autograd_ext.cpp): k x k convolution whose weight gradient comes
+    from cp2_wgrad_conv in fp32 and in the master weight's channels-last layout; forward and data gradient by MIOpen."""
+
+    @staticmethod
+    def forward(ctx, x, weight, shadow, bias, stride, pad, dil):
+        b16 = bias.to(torch.bfloat16) if bias is not None else None
+        ctx.save_for_backward(x, shadow)
+        ctx.geom, ctx.has_bias = (stride, pad, dil), bias is not None
+        return F.conv2d(x, shadow, b16, stride, pad, dil)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad, dil = ctx.geom
+        if dy.dtype != torch.bfloat16 or not dy.is_contiguous(memory_format=torch.channels_last):
+            dy = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        N, co, OH, OW = dy.shape
+        dx = dw = db = None
+        if ctx.needs_input_grad[1]:
+            dw = _bn_ops.wgrad_conv(dy, x, w.shape[2], stride, pad, dil)
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            db = dy.permute(0, 2, 3, 1).reshape(N, OH * OW, co).sum(1, dtype=torch.float32).sum(0)
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.aten.convolution_backward(dy, x, w, None, [stride, stride], [pad, pad], [dil, dil], False, [0, 0], 1,
+                                                     [True, False, False])[0]
+        return dx, dw, None, db, None, None, None
+
+
 class Conv2d(nn.Conv2d):
     """nn.Conv2d that uses `shadow_weight` -- a bf16 copy of `weight` kept current by someone else (the EMA kernel
     writes it for the key encoder, the optimizer kernel for the query encoder) -- when the input is bf16, so autocast
@@ -195,6 +224,7 @@ class Conv2d(nn.Conv2d):
     gemm_1x1 = True          # class-wide switch (A/B)
     graph_step = False       # set by engine.TrainStep(use_graph=True): warm-up steps must take the path the capture takes
     cpp_nodes = True         # autograd nodes from the C++ extension when it is built (A/B: False = the Python nodes)
+    hip_wgrad_kxk = True     # weight gradient of the k x k layers by cp2_wgrad_conv (A/B: False = MIOpen)
 
     def forward(self, x):
         w = self.shadow_weight
@@ -225,6 +255,17 @@ class Conv2d(nn.Conv2d):
                     # the Python node costs ~0.1 ms of host time per layer and step: worth it only when the step is
                     # being captured into a hipGraph (host time is then paid once)
                     return _Conv1x1Fn.apply(x, self.weight, w, self.bias, mm_fwd, ci >= 128)
+            if (Conv2d.hip_wgrad_kxk and self.kernel_size[0] == self.kernel_size[1] and self.kernel_size[0] > 1 and self.groups == 1
+                    and self.stride[0] == self.stride[1] and self.padding[0] == self.padding[1] and self.dilation[0] == self.dilation[1]
+                    and isinstance(self.padding[0], int) and self.in_channels % 64 == 0 and self.out_channels % 64 == 0
+                    and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+                    and self.weight.requires_grad and torch.is_grad_enabled()
+                    and self.weight.is_contiguous(memory_format=torch.channels_last)):
+                # k x k layers: weight gradient by cp2_wgrad_conv (fp32, deterministic) instead of MIOpen's zero-fill +
+                # atomic split-K kernel + cast, forward / data gradient unchanged (MIOpen)
+                if ext is not None:
+                    return ext.conv_kxk(x, self.weight, w, self.bias, self.stride[0], self.padding[0], self.dilation[0])
+                return _ConvKxKFn.apply(x, self.weight, w, self.bias, self.stride[0], self.padding[0], self.dilation[0])
             if self.weight.requires_grad and torch.is_grad_enabled():
                 w = ext.shadow_weight(self.weight, w) if ext is not None else _ShadowWeightFn.apply(self.weight, w)
             b = self.bias.to(torch.bfloat16) if self.bias is not None else None

@@ -677,6 +677,26 @@ def wgrad1x1(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     return dw
 
 
+def wgrad_conv(dy: torch.Tensor, x: torch.Tensor, kernel: int, stride: int, pad: int, dil: int) -> torch.Tensor:
+    """dW [CO, CI, k, k] fp32 in channels-last strides (memory order [CO][kh][kw][CI]) of a k x k convolution on
+    channels-last bf16 tensors: dy [N, CO, OH, OW], x [N, CI, H, W] (csrc/wgrad.hip, deterministic split sums)."""
+    lib = _lib.load()
+    N, CO, OH, OW = dy.shape
+    _, CI, H, W = x.shape
+    if not (dy.is_cuda and x.is_cuda and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and x.shape[0] == N
+            and dy.is_contiguous(memory_format=torch.channels_last) and x.is_contiguous(memory_format=torch.channels_last)):
+        raise _lib.Cp2LibraryError("wgrad_conv: channels-last bf16 GPU tensors of matching batch size expected")
+    S = lib.cp2_wgrad_conv_num_splits(N, OH, OW, CO, CI, kernel, kernel)
+    if S < 0:
+        _lib.check(S, "cp2_wgrad_conv_num_splits")
+    dw = torch.empty((CO, CI, kernel, kernel), dtype=torch.float32, device=dy.device, memory_format=torch.channels_last)
+    part = torch.empty(S * dw.numel(), dtype=torch.float32, device=dy.device) if S > 1 else dw
+    rc = lib.cp2_wgrad_conv(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), part.data_ptr(), N, H, W, OH, OW, CO, CI, kernel, kernel,
+                            stride, pad, dil, _stream())
+    _lib.check(rc, "cp2_wgrad_conv")
+    return dw
+
+
 # ---------------------------------------------------------------- encoder fast path: stem max-pool
 def maxpool3s2_supported(x: torch.Tensor) -> bool:
     return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] % 8 == 0

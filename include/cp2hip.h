@@ -264,6 +264,13 @@ int cp2_bn_bwd(const void* x, const void* dy, const void* y, const float* weight
  * S = cp2_wgrad1x1_num_splits(M, CO, CI); partial tiles are added in split order (deterministic, no atomics). */
 int cp2_wgrad1x1_num_splits(int M, int CO, int CI);
 int cp2_wgrad1x1(const void* dy, const void* x, float* dw, float* part, int M, int CO, int CI, void* stream);
+/* The same for a KH x KW convolution (the 3x3 convolutions of the bottlenecks and of the FCN head; groups = 1, equal
+ * stride / padding / dilation in both directions): dy [N,OH,OW,CO], x [N,H,W,CI] bf16 channels-last, dw fp32
+ * [CO][KH][KW][CI] (the memory order of a channels-last weight), OH = (H + 2 pad - dil (KH - 1) - 1) / stride + 1.
+ * part: float[S * CO * KH * KW * CI], S = cp2_wgrad_conv_num_splits(N, OH, OW, CO, CI, KH, KW).  Deterministic. */
+int cp2_wgrad_conv_num_splits(int N, int OH, int OW, int CO, int CI, int KH, int KW);
+int cp2_wgrad_conv(const void* dy, const void* x, float* dw, float* part, int N, int H, int W, int OH, int OW, int CO,
+                   int CI, int KH, int KW, int stride, int pad, int dil, void* stream);
 
 /* ---- encoder fast path (not a reference call site): the ResNet stem's MaxPool2d(3, stride 2, padding 1) ----------
  * (mmseg_/models/backbones/resnet.py:413) for channels-last bf16 activations: x [N,H,W,C], y [N,OH,OW,C] with

@@ -152,3 +152,46 @@ def test_stem_maxpool_equals_torch(N, C, H, W):
     # anything else falls through to PyTorch
     xf = torch.randn(2, 8, 9, 9, device=DEV)
     assert torch.equal(pool(xf), torch.nn.functional.max_pool2d(xf, 3, 2, 1))
+
+
+@pytest.mark.parametrize("N,ci,co,HW,k,stride,pad,dil,bias", [
+    (4, 64, 64, 56, 3, 1, 1, 1, False),       # layer1 conv2
+    (3, 128, 128, 29, 3, 2, 1, 1, False),     # a strided block (odd size: borders on every side)
+    (2, 512, 512, 14, 3, 1, 2, 2, False),     # layer4: dilation 2
+    (2, 2048, 512, 14, 3, 1, 1, 1, False),    # FCN head
+    (2, 192, 64, 9, 3, 1, 1, 1, True),        # 64-wide tiles, bias
+])
+@pytest.mark.parametrize("cpp", [True, False])
+def test_conv_kxk_weight_gradient_matches_conv2d(N, ci, co, HW, k, stride, pad, dil, bias, cpp):
+    """k x k convolution node (forward / data gradient MIOpen, weight gradient cp2_wgrad_conv in fp32) against autograd's
+    F.conv2d on the same bf16 operands: fp32 weight gradient within 2e-2 of its largest value (both sides sum bf16
+    products in different orders), same layout as the channels-last master weight."""
+    from cp2_amd import _cext
+    from cp2_amd.encoder import _ConvKxKFn
+    torch.manual_seed(ci + co + HW)
+    x = torch.randn(N, ci, HW, HW, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(co, ci, k, k, device=DEV) * (ci * k * k) ** -0.5).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(co, device=DEV) if bias else None
+    xa, wa = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ba = b.clone().requires_grad_(True) if bias else None
+    shadow = wa.detach().to(torch.bfloat16)
+    ext = _cext.load() if cpp else None
+    if cpp and ext is None:
+        pytest.skip("C++ autograd nodes not built")
+    y = ext.conv_kxk(xa, wa, shadow, ba, stride, pad, dil) if cpp else _ConvKxKFn.apply(xa, wa, shadow, ba, stride, pad, dil)
+    up = torch.randn_like(y)
+    y.backward(up)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        yr = F.conv2d(xr, wr, br, stride, pad, dil)
+    yr.backward(up)
+    close(y, yr, 2e-2, "y")
+    close(xa.grad, xr.grad, 2e-2, "dx")
+    assert wa.grad.dtype == torch.float32 and wa.grad.stride() == wa.stride()
+    close(wa.grad, wr.grad, 2e-2, "dw")
+    # exact reference of the weight gradient from the same bf16 operands in fp64
+    ref = torch.nn.grad.conv2d_weight(x.double(), w.shape, up.double(), stride=stride, padding=pad, dilation=dil)
+    close(wa.grad.double(), ref, 2e-3, "dw vs fp64")
+    if bias:
+        close(ba.grad, br.grad, 2e-2, "db")
