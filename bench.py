@@ -68,12 +68,12 @@ def parse():
 
 def count_flops_per_image(model, batch):
     """FLOPs of one step (q forward+backward, k forward, loss GEMMs excluded) via torch's flop counter.  The counter only
-    sees ATen operators, so the pass runs with every convolution on the ATen path (the product path sends the 1x1
-    weight gradients through cp2_wgrad1x1, which it would not count)."""
+    sees ATen operators, so the pass runs with every convolution on the ATen path (the product path sends the 1x1 and
+    k x k weight gradients through cp2_wgrad1x1 / cp2_wgrad_conv, which it would not count)."""
     from torch.utils.flop_counter import FlopCounterMode
     from cp2_amd.encoder import Conv2d
-    saved = (Conv2d.cpp_nodes, Conv2d.gemm_1x1)
-    Conv2d.cpp_nodes, Conv2d.gemm_1x1 = False, False
+    saved = (Conv2d.cpp_nodes, Conv2d.gemm_1x1, Conv2d.hip_wgrad_kxk)
+    Conv2d.cpp_nodes, Conv2d.gemm_1x1, Conv2d.hip_wgrad_kxk = False, False, False
     try:
         with FlopCounterMode(display=False) as fc:
             with torch.autocast("cuda", dtype=torch.bfloat16):
@@ -82,7 +82,7 @@ def count_flops_per_image(model, batch):
                     model.encoder_k(batch["img_b"])
             y.float().mean().backward()
     finally:
-        Conv2d.cpp_nodes, Conv2d.gemm_1x1 = saved
+        Conv2d.cpp_nodes, Conv2d.gemm_1x1, Conv2d.hip_wgrad_kxk = saved
     model.encoder_q.zero_grad(set_to_none=True)
     return fc.get_total_flops() / batch["img_a"].shape[0]
 
@@ -190,6 +190,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     loss_val = float(loss)
+    if use_graph and not (loss_val == loss_val and abs(loss_val) < 1e30):
+        # safety net of the captured step: a non-finite loss means a replay fault slipped between two verifications.
+        # The state is lost, so the measurement is repeated eagerly in a child process (never exec from a process that
+        # has initialised the GPU) and its line is this run's result.
+        import subprocess
+        print("bench.py: captured step ended with a non-finite loss; repeating the run eagerly", file=sys.stderr)
+        argv = [a for a in sys.argv[1:]]
+        if "--graph" in argv:
+            i = argv.index("--graph"); del argv[i:i + 2]
+        raise SystemExit(subprocess.call([sys.executable, os.path.abspath(__file__)] + argv + ["--graph", "off"]))
     assert loss_val == loss_val, "loss is NaN"
 
     prof, ops.PROFILE = ops.PROFILE or {}, None

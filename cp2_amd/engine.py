@@ -72,12 +72,15 @@ class TrainStep:
     if the capture itself fails, the state is rolled back and the step continues eagerly (`self.fallback_reason`)."""
 
     def __init__(self, model, optimizer, use_graph: bool = False, warmup_steps: int = 3, verify: bool = True,
-                 reverify_every: int = 200):
+                 reverify_every: int = 200, verify_first: int = 3):
         self.model, self.optimizer = model, optimizer
         self.use_graph, self.warmup_steps, self.verify = use_graph, warmup_steps, verify
         # the replay fault of DESIGN.md section 5 depends on what the graph's memory pool holds, so a replay that was
         # right once can go wrong later: with verify on, every `reverify_every`-th replay is checked again
         self.reverify_every = reverify_every
+        # ... and both faults found so far (MIOpen's atomic weight gradients, ATen's semaphore reduction) showed up on the
+        # SECOND replay, not the first: the first `verify_first` replays are all checked
+        self.verify_first = verify_first
         self._replays = 0
         self.fallback_reason = None
         if use_graph:
@@ -134,7 +137,7 @@ class TrainStep:
             self.static[k].copy_(batch[k])
         self.static_idx.copy_(self._shuffle_index(n_all, dev))
         self._replays += 1
-        if self.verify and self.reverify_every and self._replays % self.reverify_every == 0:
+        if self.verify and ((self.reverify_every and self._replays % self.reverify_every == 0) or self._replays < self.verify_first):
             return self._checked_replay(batch)
         self.graph.replay()
         self._after_replay()
@@ -253,10 +256,12 @@ class TrainStep:
         return snap, ref_loss, ref_grads
 
     def _compare(self, params, ref_loss, ref_grads):
-        """None if the replay agrees with the eager probe.  Per tensor: L2 error <= 5e-2 |g| (bf16 encoders with
-        atomically accumulated MIOpen weight gradients differ by ~1e-2 between two eager runs) and no element further
+        """None if the replay agrees with the eager probe.  Per tensor: L2 error <= 1e-1 |g| and no element further
         than 0.25 max|g| from the eager value, both with a floor of 5e-4 of the whole gradient's norm; non-finite
-        anywhere fails.  (Round 1 accepted 0.2 |g|, which only caught garbage.)"""
+        anywhere fails.  Two eager runs of the bf16 encoders differ by ~1e-2 per tensor (MIOpen data-gradient kernels
+        that accumulate in bf16 atomics), more at the end of the chain: the stem's weight gradient of the 8-image test
+        model reached 5.2e-2 once in four runs, so 5e-2 was too tight a bound for a check that now runs on the first
+        three replays; both faults this check exists for produced non-finite values.  (Round 1 accepted 0.2 |g|.)"""
         if not bool(torch.isfinite(self.static_loss)) or abs(float(self.static_loss) - float(ref_loss)) > 2e-2 * max(1.0, abs(float(ref_loss))):
             return f"loss {float(self.static_loss):.5f} vs eager {float(ref_loss):.5f}"
         # a few gradients (the first BatchNorm's bias) are sums that cancel to ~1e-3 of the others: their run-to-run
@@ -267,7 +272,7 @@ class TrainStep:
                 continue
             a, b = p.grad.float(), g.float()
             den, err, amax = float(b.norm()), float((a - b).norm()), float((a - b).abs().max())
-            if not (err == err) or err > max(5e-2 * den, 5e-4 * total) + 1e-6 or amax > max(0.25 * float(b.abs().max()), 5e-4 * total) + 1e-6:
+            if not (err == err) or err > max(1e-1 * den, 5e-4 * total) + 1e-6 or amax > max(0.25 * float(b.abs().max()), 5e-4 * total) + 1e-6:
                 return f"gradient of a {tuple(p.shape)} parameter: |replay - eager| = {err:.3e}, |eager| = {den:.3e}, max |diff| = {amax:.3e}"
         return None
 

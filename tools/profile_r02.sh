@@ -9,7 +9,7 @@ timeout -k 10 500 rocprofv3 --kernel-trace --stats -d /tmp/p1 -o b --output-form
 cp /tmp/p1/b_kernel_stats.csv $O/r02_bench_n1_kernel_stats.csv
 python3 tools/step_breakdown.py /tmp/p1/b_kernel_trace.csv 20 > $O/r02_bench_n1_step_breakdown.txt
 python3 tools/kstats.py /tmp/p1/b_kernel_trace.csv rowkey quantile dense_ enqueue feat_ pool_ corr_iou compose strided gather_rows ema_ sgd_ > $O/r02_bench_n1_loss_kernels.txt
-python3 tools/kstats.py /tmp/p1/b_kernel_trace.csv wgrad maxpool igemm_wrw SubTensor reduce_kernel > $O/r02_bench_n1_encoder_extras.txt
+python3 tools/kstats.py /tmp/p1/b_kernel_trace.csv wgrad maxpool reduce_kernel > $O/r02_bench_n1_encoder_extras.txt
 # 2. the MFMA-bound sizes (config 4 / 5) and the instance kernel alone
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d /tmp/p2 -o k --output-format csv -- python3 tools/bench_kernels.py > $O/r02_bench_kernels.log 2>&1 || exit 1
 cp /tmp/p2/k_kernel_stats.csv $O/r02_kernels_kernel_stats.csv

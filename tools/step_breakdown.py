@@ -21,9 +21,10 @@ for n,(d,c) in top[:int(sys.argv[3]) if len(sys.argv)>3 else 45]:
 # category roll-up (ms per step)
 def cat(n):
     if n.startswith(('bn_', 'void bn_')): return 'fused BN kernels (csrc/bn.hip)'
-    if 'wgrad' in n: return '1x1-convolution weight gradient (csrc/wgrad.hip)'
+    if 'wgrad' in n: return 'convolution weight gradients, 1x1 and k x k (csrc/wgrad.hip)'
+    if 'maxpool3s2' in n: return 'stem max-pool (csrc/pool.hip)'
     if any(k in n for k in ('ema_flat', 'sgd_flat', 'bf16_image')): return 'EMA + optimizer kernels (csrc/ema.hip, sgd.hip)'
-    if any(k in n for k in ('rowkey', 'dense_', 'masked_quantile', 'feat_', 'pool_', 'compose', 'strided_gather', 'gather_rows',
+    if any(k in n for k in ('rowkey', 'dense_', 'quantile', 'feat_', 'pool_', 'compose', 'strided_gather', 'gather_rows',
                             'corr_iou', 'enqueue', 'keys_split', 'mean_kernel')): return 'loss-section kernels (csrc/*.hip)'
     if any(k in n for k in ('igemm', 'ck::', '_ZN2ck', 'SubTensorOp', 'Cijk', 'miopen', 'MIOpen', 'naive_conv', 'gemm')): return 'MIOpen / CK / hipBLASLt (convolutions, GEMMs)'
     if 'rocclr' in n: return 'runtime fills / copies'
