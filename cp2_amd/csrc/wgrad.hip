@@ -11,6 +11,7 @@
 // the fp32 result is the gradient of the fp32 master weight directly (no bf16 round trip, no cast kernel).
 // HBM / L2 bound: 2 bytes * M * (CO + CI) per output-tile row/column pass.
 #include "common.hpp"
+#include <stdlib.h>
 
 typedef float wg_f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
@@ -176,7 +177,17 @@ static int wgrad_geom(int M, int CO, int CI, int* F, int* S, int* rows, int taps
     *F = (CO % 128 == 0 && CI % 128 == 0) ? 2 : 1;
     const int T = 64 * *F;
     const int64_t tiles = (int64_t)(CO / T) * (CI / T) * taps;
-    int64_t s = (512 + tiles - 1) / tiles;                 // two workgroups per CU in all (measured: 512 < 768 < 1024 < 1536
+    static int target = 0, target_conv = 0;                // tuning knobs (workgroups in all): CP2_WGRAD_TARGET / _CONV
+    if (!target) {
+        const char* e = getenv("CP2_WGRAD_TARGET");
+        const char* c = getenv("CP2_WGRAD_TARGET_CONV");
+        target = e ? atoi(e) : 512;
+        target_conv = c ? atoi(c) : 512;
+        if (target < 1) target = 512;
+        if (target_conv < 1) target_conv = 512;
+    }
+    const int tg = taps > 1 ? target_conv : target;
+    int64_t s = (tg + tiles - 1) / tiles;                  // two workgroups per CU in all (measured: 512 < 768 < 1024 < 1536
                                                            // in total time over the ResNet-50 shapes, 398 / 423 / 433 / 448 us)
     const int64_t max_s = (M + 2 * WG_KM - 1) / (2 * WG_KM);
     if (s > max_s) s = max_s;
