@@ -187,6 +187,10 @@ static int wgrad_geom(int M, int CO, int CI, int* F, int* S, int* rows, int taps
         if (target_conv < 1) target_conv = 512;
     }
     const int tg = taps > 1 ? target_conv : target;
+    // measured and rejected (round 2): a two-deep register ring (loads two stages ahead) -- 128-142 VGPRs besides the 64
+    // accumulators drop the F = 2 kernels to 1-2 waves per SIMD and the FCN head's 3x3 layers went 250 -> 562 us; the
+    // workgroup count for the k x k form (tools/wgrad_conv_sweep.py): 256 / 512 / 768 / 1024 / 1536 -> 1459 / 1250 /
+    // 1322 / 1319 / 1405 us per step
     int64_t s = (tg + tiles - 1) / tiles;                  // two workgroups per CU in all (measured: 512 < 768 < 1024 < 1536
                                                            // in total time over the ResNet-50 shapes, 398 / 423 / 433 / 448 us)
     const int64_t max_s = (M + 2 * WG_KM - 1) / (2 * WG_KM);
