@@ -494,6 +494,9 @@ __global__ __launch_bounds__(QT3) void quantile_final_kernel(QuantJobs jobs) {
 // encoder lie in a band so narrow that a 12-bit float prefix holds most of a row (the candidate lists overflow):
 // measured inside the step 74 us for the three launches against 66 us for this kernel.  The chunked form above is for
 // rows a single CU cannot stream (BASELINE config 4: 16.7 M elements per row).
+// (Measured and rejected: 8 replicas per histogram bin, lane % 8, against same-address serialisation of the LDS atomics
+// on narrow-band rows -- 70 us instead of 63-66: the passes are bound by their ~30 VALU instructions per element on the
+// one CU a row has, not by atomic conflicts.)
 constexpr int QROW_MAX = CP2_QUANTILES_ROW_MAX;
 __global__ __launch_bounds__(QT3) void quantiles_row_kernel(QuantJobs jobs) {
     int jsel = 0;
