@@ -6,24 +6,26 @@
 // (12 + 10 + 10 bits), all requested quantiles of a row together, then the interpolation of
 // torch.quantile(..., interpolation='linear'):  rank = q*(n-1) in fp32, lerp(v_lo, v_hi, frac).
 //
-// Round 1 / early round 2 ran ONE workgroup per row through three passes over the row: 96 workgroups on 256 CUs, each
-// VALU-bound on its CU (66 us per step at 32 x 65536 + 2 x 32 x 196^2; at BASELINE config 4, 16 rows of 16.7 M
-// elements, it would leave the chip idle).  Now every row is cut into 8192-element chunks and the work is three launches:
-//   K1  quantile_hist_kernel     one workgroup per chunk: LDS histogram of the top 12 bits, non-zero bins added to the
-//                                row's global histogram
-//   K2  quantile_compact_kernel  one workgroup per chunk: finds the row's bin of every quantile from that histogram
-//                                (every workgroup of the row, redundantly), appends its chunk's elements of those bins
-//                                to the row's candidate lists (staged in LDS, ONE returning atomic per workgroup and
-//                                quantile), adds their next 10 bits to the row's second-level histograms and tracks the
-//                                smallest key above each bin (the interpolation partner when a bin's maximum is selected)
-//   K3  quantile_final_kernel    one workgroup per row: second- and third-level select over the candidates only (about
-//                                1.5 % of a row for Gaussian-like logits; the whole row again if a list overflowed),
-//                                interpolation, and the row's workspace is left zeroed for the next call
+// Two forms.  Rows of at most CP2_QUANTILES_ROW_MAX elements (the training step: 32 x 65536 queue logits + 2 x 32 x 196^2
+// dense pairs): quantiles_row_kernel, ONE launch, one workgroup per row through the three levels (66 us per step).
+// Longer rows (BASELINE config 4: 16 rows of 16.7 M dense logits) are cut into 8192-element chunks and every level is
+// a chunk-parallel histogram pass with a tiny per-row select between the passes:
+//   K1  quantile_hist_kernel<0>   chunk: LDS histogram of the top 12 bits         -> global hist0 (atomic adds)
+//   S1  quantile_select_kernel<0> row:   rank -> (bin, rank in bin) per quantile, number of kept elements
+//   K2  quantile_hist_kernel<1>   chunk: next 10 bits of the elements in the selected first-level bins -> hist1
+//   S2  quantile_select_kernel<1> row
+//   K3  quantile_hist_kernel<2>   chunk: last 10 bits of the elements with the selected 22-bit prefix -> hist2, and the
+//                                 smallest key above that prefix (the interpolation partner when a bin's maximum is hit)
+//   S3  quantile_select_kernel<2> row:   final key, partner, interpolation; the row's workspace is left zeroed
+// Every level counts ALL matching elements, so the cost does not depend on the data: an earlier form of this path
+// compacted the first-level candidates and finished them in one workgroup per row -- 1.2 ms on Gaussian test data, but
+// the dense logits of a freshly initialised encoder are a handful of distinct fp32 values next to 1.0, every candidate
+// list overflowed, and the per-row fallback cost 10.9-12.7 ms per step at config 4 (19 % of the step).
 // Integer counting only: the result does not depend on the order in which atomics arrive (bit-exact vs torch.nanquantile).
 // The logits are read from memory, i.e. they ARE materialised by the loss kernels when quartile logging is on: building
 // the first histogram inside the loss kernels would need 32 rows x 4096 bins of LDS per tile (512 KB), and recomputing
-// the P x P logits in K1 and K2 costs two more MFMA passes (2 x 0.44 ms at config 4) against 0.27 ms for writing them
-// once and reading them twice at HBM speed.
+// the P x P logits in every pass costs three more MFMA passes (3 x 0.44 ms at config 4) against 0.36 ms for writing
+// them once and reading them three times at HBM speed.
 #include "common.hpp"
 #include <math.h>
 
@@ -34,8 +36,6 @@ struct QuantArgs {
     float* out;                                            // [NQ][R] (torch.quantile layout)
     int R;
     int chunks;                                            // ceil(N / QCHUNK)
-    int cap;                                               // candidate slots per (row, quantile)
-    int64_t cand_off;                                      // offset (in words) of this job's candidate lists in the workspace
 };
 
 __device__ __forceinline__ unsigned f2key(float f) {
@@ -48,10 +48,9 @@ __device__ __forceinline__ float key2f(unsigned k) {
 
 constexpr int QMAX = 4;                   // quantiles per call
 constexpr int QB0 = 4096, QB1 = 1024;     // bins of the first / second and third level
-constexpr int QCHUNK = 8192;              // elements per workgroup in K1 / K2
-constexpr int QT1 = 256;                  // threads per workgroup in K1 / K2
-constexpr int QT3 = 1024;                 // threads per workgroup in K3
-constexpr int QSTAGE = 1024;              // candidates one chunk may stage per quantile before the row falls back
+constexpr int QCHUNK = 8192;              // elements per workgroup of the chunk-parallel passes
+constexpr int QT1 = 256;                  // threads per workgroup of the chunk-parallel passes
+constexpr int QT3 = 1024;                 // threads per workgroup of the per-row kernels
 constexpr int QJOBS = 4;
 constexpr unsigned QNONE = 0xFFFFFFFFu;
 
@@ -59,16 +58,16 @@ struct QuantJobs {
     QuantArgs job[QJOBS];
     int first_row[QJOBS + 1];              // rows of job j: [first_row[j], first_row[j+1])
     int first_chunk[QJOBS + 1];            // chunk workgroups of job j
-    // workspace (device, zero between calls): per global row rt
+    // workspace of the chunked form (device, zero between calls): per global row rt
     unsigned* hist0;                       // [rows][QB0]
     unsigned* hist1;                       // [rows][QMAX][QB1]
-    unsigned* ccount;                      // [rows][QMAX] candidates appended
-    unsigned* above;                       // [rows][QMAX] max over ~key of the elements above the bin (0 = none)
-    unsigned* cand;                        // per job: [R][NQ][cap] keys
+    unsigned* hist2;                       // [rows][QMAX][QB1]
+    unsigned* above;                       // [rows][QMAX] max over ~key of the elements above the 22-bit prefix (0 = none)
+    unsigned* sel;                         // [rows][QSEL]: n | per quantile: prefix so far, rank inside it
 };
-
-// per-row workspace header words: hist0 | hist1 | ccount | above
-constexpr int64_t QROW_WORDS = QB0 + QMAX * QB1 + 2 * QMAX;
+constexpr int QSEL = 1 + 2 * QMAX;
+// per-row workspace words: hist0 | hist1 | hist2 | above | sel
+constexpr int64_t QROW_WORDS = QB0 + 2 * QMAX * QB1 + QMAX + QSEL;
 
 template <int NT>
 __device__ __forceinline__ unsigned block_scan_incl(unsigned v, unsigned* wtot) {
@@ -244,248 +243,149 @@ __device__ __forceinline__ void locate(const unsigned (&hv)[BPT], unsigned excl,
     }
 }
 
-// ---- K1: first-level histogram of one chunk -> the row's global histogram
+// ---- chunk-parallel histogram of level LEVEL (0: top 12 bits of every kept element; 1: next 10 bits of the elements in
+// the selected first-level bin; 2: last 10 bits of the elements with the selected 22-bit prefix + smallest key above it)
+template <int LEVEL>
 __global__ __launch_bounds__(QT1) void quantile_hist_kernel(QuantJobs jobs) {
-    __shared__ unsigned h[QB0];
-    const int jsel = job_of(jobs.first_chunk, (int)blockIdx.x);
-    const QuantArgs& a = jobs.job[jsel];
-    const int c = (int)blockIdx.x - jobs.first_chunk[jsel], r = c / a.chunks, s = c - r * a.chunks;
-    const int tid = threadIdx.x;
-    const int begin = s * QCHUNK, end = min(a.N, begin + QCHUNK);
-    ChunkData<QT1> d;
-    chunk_load<QT1>(a, r, begin, end, d);                  // every load of the workgroup in flight
-    for (int i = tid; i < QB0; i += QT1) h[i] = 0;
-    __syncthreads();
-    chunk_visit<QT1>(a, r, begin, end, d, [&](unsigned k) { atomicAdd(&h[k >> 20], 1u); });
-    __syncthreads();
-    unsigned* g = jobs.hist0 + (int64_t)(jobs.first_row[jsel] + r) * QB0;
-    for (int i = tid; i < QB0; i += QT1) {
-        const unsigned v = h[i];
-        if (v) atomicAdd(&g[i], v);
-    }
-}
-
-// ---- K2: candidates of one chunk
-__global__ __launch_bounds__(QT1) void quantile_compact_kernel(QuantJobs jobs) {
-    __shared__ unsigned h1[QMAX][QB1];
-    __shared__ unsigned stage[QMAX][QSTAGE];
-    __shared__ unsigned wtot[QT1 / 64];
-    __shared__ unsigned sh_bin[QMAX], sh_kk[QMAX], sh_cnt[QMAX], sh_min[QMAX], sh_base[QMAX], sh_n;
+    constexpr int NB = LEVEL == 0 ? QB0 : QMAX * QB1;
+    __shared__ unsigned h[NB];
+    __shared__ unsigned sh_min[QMAX];
     const int jsel = job_of(jobs.first_chunk, (int)blockIdx.x);
     const QuantArgs& a = jobs.job[jsel];
     const int c = (int)blockIdx.x - jobs.first_chunk[jsel], r = c / a.chunks, s = c - r * a.chunks;
     const int tid = threadIdx.x, NQ = a.NQ;
     const int64_t rt = jobs.first_row[jsel] + r;
+    const unsigned* sel = jobs.sel + rt * QSEL;
+    if (LEVEL > 0 && sel[0] == 0u) return;                 // nothing kept in this row (workgroup-uniform)
     const int begin = s * QCHUNK, end = min(a.N, begin + QCHUNK);
-    // one memory round trip: the row's first-level histogram (16 bins per thread) and this chunk's data
-    constexpr int BPT = QB0 / QT1;
-    unsigned hv[BPT];
-    {
-        const uint4* g4 = reinterpret_cast<const uint4*>(jobs.hist0 + rt * QB0 + BPT * tid);
-#pragma unroll
-        for (int u = 0; u < BPT / 4; ++u) {
-            const uint4 t = g4[u];
-            hv[4 * u] = t.x; hv[4 * u + 1] = t.y; hv[4 * u + 2] = t.z; hv[4 * u + 3] = t.w;
-        }
-    }
     ChunkData<QT1> d;
-    chunk_load<QT1>(a, r, begin, end, d);
-    if (tid < QMAX) { sh_cnt[tid] = 0; sh_min[tid] = QNONE; sh_bin[tid] = QNONE; }
-    for (int i = tid; i < QMAX * QB1; i += QT1) (&h1[0][0])[i] = 0;
-    unsigned tot = 0;
+    chunk_load<QT1>(a, r, begin, end, d);                  // every load of the workgroup in flight
+    unsigned pre[QMAX], mn[QMAX];
 #pragma unroll
-    for (int u = 0; u < BPT; ++u) tot += hv[u];
-    const unsigned incl = block_scan_incl<QT1>(tot, wtot), excl = incl - tot;
-    if (tid == QT1 - 1) sh_n = incl;
+    for (int j = 0; j < QMAX; ++j) { pre[j] = (LEVEL > 0 && j < NQ) ? sel[1 + 2 * j] : QNONE; mn[j] = QNONE; }
+    for (int i = tid; i < NB; i += QT1) h[i] = 0;
+    if (LEVEL == 2 && tid < QMAX) sh_min[tid] = QNONE;
     __syncthreads();
-    const unsigned n = sh_n;
-    if (n == 0) return;                                    // nothing kept in this row: K3 writes NaN
-    for (int j = 0; j < NQ; ++j)
-        locate<BPT>(hv, excl, incl, (unsigned)floorf(a.q[j] * (float)(n - 1)), &sh_bin[j], &sh_kk[j]);
-    __syncthreads();
-    unsigned bin[QMAX], mn[QMAX];
-#pragma unroll
-    for (int j = 0; j < QMAX; ++j) { bin[j] = j < NQ ? sh_bin[j] : QNONE; mn[j] = QNONE; }
     chunk_visit<QT1>(a, r, begin, end, d, [&](unsigned k) {
-        const unsigned top = k >> 20;
+        if (LEVEL == 0) {
+            atomicAdd(&h[k >> 20], 1u);
+        } else {
+            const unsigned top = LEVEL == 1 ? (k >> 20) : (k >> 10);
+            const unsigned bin = LEVEL == 1 ? ((k >> 10) & (QB1 - 1)) : (k & (QB1 - 1));
 #pragma unroll
-        for (int j = 0; j < QMAX; ++j) {
-            if (top == bin[j]) {
-                const unsigned slot = atomicAdd(&sh_cnt[j], 1u);
-                if (slot < QSTAGE) stage[j][slot] = k;
-                atomicAdd(&h1[j][(k >> 10) & (QB1 - 1)], 1u);
-            } else if (j < NQ && top > bin[j]) {
-                mn[j] = min(mn[j], k);
+            for (int j = 0; j < QMAX; ++j) {
+                if (top == pre[j]) atomicAdd(&h[j * QB1 + bin], 1u);
+                else if (LEVEL == 2 && j < NQ && top > pre[j]) mn[j] = min(mn[j], k);
             }
         }
     });
+    if (LEVEL == 2) {
 #pragma unroll
-    for (int j = 0; j < QMAX; ++j) {
-        unsigned m = mn[j];
+        for (int j = 0; j < QMAX; ++j) {
+            unsigned m = mn[j];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, off, 64));
-        if ((tid & 63) == 0 && m != QNONE) atomicMin(&sh_min[j], m);
-    }
-    __syncthreads();
-    unsigned* ccount = jobs.ccount + rt * QMAX;
-    if (tid < NQ) {
-        const unsigned cnt = sh_cnt[tid];
-        // a chunk with more matches than it can stage marks the row's count: K3 then re-reads the row itself
-        unsigned base = 0;
-        if (cnt > QSTAGE) atomicOr(&ccount[tid], 0x80000000u);
-        else if (cnt) base = atomicAdd(&ccount[tid], cnt);
-        sh_base[tid] = base;
-        if (sh_min[tid] != QNONE) atomicMax(&jobs.above[rt * QMAX + tid], ~sh_min[tid]);
-    }
-    unsigned* g1 = jobs.hist1 + rt * QMAX * QB1;
-    for (int j = 0; j < NQ; ++j)
-        for (int i = tid; i < QB1; i += QT1) {
-            const unsigned v = h1[j][i];
-            if (v) atomicAdd(&g1[j * QB1 + i], v);
-        }
-    __syncthreads();
-    for (int j = 0; j < NQ; ++j) {
-        const unsigned cnt = sh_cnt[j], base = sh_base[j];
-        if (cnt <= QSTAGE) {
-            unsigned* dst = jobs.cand + a.cand_off + ((int64_t)r * NQ + j) * a.cap;
-            for (unsigned i = tid; i < cnt; i += QT1)
-                if (base + i < (unsigned)a.cap) dst[base + i] = stage[j][i];
+            for (int off = 32; off > 0; off >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, off, 64));
+            if ((tid & 63) == 0 && m != QNONE) atomicMin(&sh_min[j], m);
         }
     }
+    __syncthreads();
+    unsigned* g = LEVEL == 0 ? jobs.hist0 + rt * QB0 : (LEVEL == 1 ? jobs.hist1 : jobs.hist2) + rt * QMAX * QB1;
+    const int nb = LEVEL == 0 ? QB0 : NQ * QB1;
+    for (int i = tid; i < nb; i += QT1) {
+        const unsigned v = h[i];
+        if (v) atomicAdd(&g[i], v);
+    }
+    if (LEVEL == 2 && tid < NQ && sh_min[tid] != QNONE) atomicMax(&jobs.above[rt * QMAX + tid], ~sh_min[tid]);
 }
 
-// ---- K3: one workgroup per row: levels two and three over the candidates, interpolation, workspace clean-up
-__global__ __launch_bounds__(QT3) void quantile_final_kernel(QuantJobs jobs) {
-    __shared__ unsigned h2[QMAX][QB1];
+// ---- per-row select after level LEVEL: one workgroup per row
+template <int LEVEL>
+__global__ __launch_bounds__(QT3) void quantile_select_kernel(QuantJobs jobs) {
     __shared__ unsigned wtot[QT3 / 64];
-    __shared__ unsigned sh_bin0[QMAX], sh_kk[QMAX], sh_bin1[QMAX], sh_bin2[QMAX], sh_min[QMAX], sh_next[QMAX], sh_n;
+    __shared__ unsigned sh_bin[QMAX], sh_kk[QMAX], sh_next[QMAX], sh_n;
     const int jsel = job_of(jobs.first_row, (int)blockIdx.x);
     const QuantArgs& a = jobs.job[jsel];
     const int r = (int)blockIdx.x - jobs.first_row[jsel], tid = threadIdx.x, NQ = a.NQ;
     const int64_t rt = blockIdx.x;
-    unsigned* g0 = jobs.hist0 + rt * QB0;
-    unsigned* g1 = jobs.hist1 + rt * QMAX * QB1;
-    unsigned* ccount = jobs.ccount + rt * QMAX;
-    unsigned* above = jobs.above + rt * QMAX;
-    // one memory round trip: both histogram levels, the candidate counts and the first candidate of every thread
-    constexpr int BPT = QB0 / QT3;
-    static_assert(BPT == 4 && QB1 == QT3, "one uint4 of first-level bins and one second-level bin per thread");
-    unsigned hv[BPT], h1v[QMAX], cnt[QMAX], c0[QMAX];
-    {
-        const uint4 t = reinterpret_cast<const uint4*>(g0)[tid];
-        hv[0] = t.x; hv[1] = t.y; hv[2] = t.z; hv[3] = t.w;
-    }
-    bool overflow = false;
-#pragma unroll
-    for (int j = 0; j < QMAX; ++j) {
-        h1v[j] = j < NQ ? g1[j * QB1 + tid] : 0u;
-        cnt[j] = j < NQ ? ccount[j] : 0u;
-        if (cnt[j] > (unsigned)a.cap) overflow = true;
-        c0[j] = 0;
-        if (j < NQ && (unsigned)tid < cnt[j] && cnt[j] <= (unsigned)a.cap)
-            c0[j] = (jobs.cand + a.cand_off + ((int64_t)r * NQ + j) * a.cap)[tid];
-    }
-    if (tid < QMAX) { sh_min[tid] = QNONE; sh_next[tid] = QNONE; }
-    for (int i = tid; i < QMAX * QB1; i += QT3) (&h2[0][0])[i] = 0;
-    unsigned tot = hv[0] + hv[1] + hv[2] + hv[3];
-    unsigned incl = block_scan_incl<QT3>(tot, wtot), excl = incl - tot;
-    if (tid == QT3 - 1) sh_n = incl;
-    __syncthreads();
-    const unsigned n = sh_n;
-    if (n == 0) {                                          // nothing kept: K1 added nothing, K2 returned early
-        if (tid < NQ) a.out[(int64_t)tid * a.R + r] = NAN;
+    unsigned* sel = jobs.sel + rt * QSEL;
+    if (LEVEL == 0) {
+        constexpr int BPT = QB0 / QT3;
+        unsigned* g0 = jobs.hist0 + rt * QB0;
+        unsigned hv[BPT];
+        {
+            const uint4 t = reinterpret_cast<const uint4*>(g0)[tid];
+            hv[0] = t.x; hv[1] = t.y; hv[2] = t.z; hv[3] = t.w;
+        }
+        const unsigned tot = hv[0] + hv[1] + hv[2] + hv[3];
+        const unsigned incl = block_scan_incl<QT3>(tot, wtot), excl = incl - tot;
+        if (tid == QT3 - 1) sh_n = incl;
+        __syncthreads();
+        const unsigned n = sh_n;
+        if (n > 0) {
+            for (int j = 0; j < NQ; ++j)
+                locate<BPT>(hv, excl, incl, (unsigned)floorf(a.q[j] * (float)(n - 1)), &sh_bin[j], &sh_kk[j]);
+        }
+        __syncthreads();
+        if (tid == 0) sel[0] = n;
+        if (n > 0 && tid < NQ) { sel[1 + 2 * tid] = sh_bin[tid]; sel[2 + 2 * tid] = sh_kk[tid]; }
+        if (n == 0 && tid < NQ) a.out[(int64_t)tid * a.R + r] = NAN;        // nothing kept: the later passes skip the row
+        reinterpret_cast<uint4*>(g0)[tid] = make_uint4(0u, 0u, 0u, 0u);     // hist0 is done: zero for the next call
+        if (n == 0 && tid == 0) sel[0] = 0;
         return;
     }
-    for (int j = 0; j < NQ; ++j)
-        locate<BPT>(hv, excl, incl, (unsigned)floorf(a.q[j] * (float)(n - 1)), &sh_bin0[j], &sh_kk[j]);
-    // level two: the 10 bits below, from the histograms K2 accumulated (rank inside the first-level bin = sh_kk)
+    const unsigned n = sel[0];
+    if (n == 0) return;                                    // (the level-0 select wrote NaN; nothing was added anywhere)
+    unsigned* g = (LEVEL == 1 ? jobs.hist1 : jobs.hist2) + rt * QMAX * QB1;
+    unsigned hvj[QMAX], pre[QMAX], kk[QMAX];
+#pragma unroll
+    for (int j = 0; j < QMAX; ++j) {                       // one memory round trip for everything this kernel reads
+        hvj[j] = j < NQ ? g[j * QB1 + tid] : 0u;
+        pre[j] = j < NQ ? sel[1 + 2 * j] : 0u;
+        kk[j] = j < NQ ? sel[2 + 2 * j] : 0u;
+    }
+    if (tid < QMAX) sh_next[tid] = QNONE;
 #pragma unroll
     for (int j = 0; j < QMAX; ++j) {
         if (j < NQ) {
-            const unsigned one[1] = {h1v[j]};
-            incl = block_scan_incl<QT3>(h1v[j], wtot);     // its barriers also publish sh_kk[j] of the level above
-            const unsigned lo = sh_kk[j];
-            __syncthreads();                               // everyone has read sh_kk[j] before it is rewritten
-            locate<1>(one, incl - h1v[j], incl, lo, &sh_bin1[j], &sh_kk[j]);
+            const unsigned one[1] = {hvj[j]};
+            const unsigned incl = block_scan_incl<QT3>(hvj[j], wtot);
+            locate<1>(one, incl - hvj[j], incl, kk[j], &sh_bin[j], &sh_kk[j]);
         }
     }
     __syncthreads();
-    unsigned pre[QMAX], mn[QMAX];
-#pragma unroll
-    for (int j = 0; j < QMAX; ++j) {
-        pre[j] = j < NQ ? ((sh_bin0[j] << 10) | sh_bin1[j]) : QNONE;
-        mn[j] = QNONE;
-    }
-    // level three for quantile j (j is a compile-time index wherever this is used)
-#define CP2_Q_VISIT(k, j)                                                                   \
-    do {                                                                                    \
-        const unsigned top_ = (k) >> 10;                                                    \
-        if (top_ == pre[j]) atomicAdd(&h2[j][(k) & (QB1 - 1)], 1u);                         \
-        else if (top_ > pre[j]) mn[j] = min(mn[j], (k)); /* larger key, same first bin */   \
-    } while (0)
-    if (!overflow) {
-#pragma unroll
-        for (int j = 0; j < QMAX; ++j) {
-            if (j < NQ) {
-                const unsigned* src = jobs.cand + a.cand_off + ((int64_t)r * NQ + j) * a.cap;
-                if ((unsigned)tid < cnt[j]) CP2_Q_VISIT(c0[j], j);
-                for (unsigned i = tid + QT3; i < cnt[j]; i += QT3) { const unsigned k = src[i]; CP2_Q_VISIT(k, j); }
-            }
-        }
-    } else {                                               // a candidate list overflowed: the row itself, filtered
-        for_each_kept<QT3>(a, r, 0, a.N, [&](unsigned k) {
-#pragma unroll
-            for (int j = 0; j < QMAX; ++j)
-                if (j < NQ && (k >> 20) == (pre[j] >> 10)) CP2_Q_VISIT(k, j);
-        });
-    }
-#undef CP2_Q_VISIT
-#pragma unroll
-    for (int j = 0; j < QMAX; ++j) {
-        unsigned m = mn[j];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, off, 64));
-        if ((tid & 63) == 0 && m != QNONE) atomicMin(&sh_min[j], m);
-    }
-    __syncthreads();
-    for (int j = 0; j < NQ; ++j) {
-        const unsigned hvj = h2[j][tid];
-        const unsigned one[1] = {hvj};
-        incl = block_scan_incl<QT3>(hvj, wtot);
-        const unsigned lo = sh_kk[j];
-        __syncthreads();
-        locate<1>(one, incl - hvj, incl, lo, &sh_bin2[j], &sh_kk[j]);
-        __syncthreads();
+    if (LEVEL == 1) {
+        if (tid < NQ) { sel[1 + 2 * tid] = (pre[tid] << 10) | sh_bin[tid]; sel[2 + 2 * tid] = sh_kk[tid]; }
+    } else {
         // the next non-empty bin above the selected one (the partner when the selected key is not repeated)
-        if (hvj != 0 && (unsigned)tid > sh_bin2[j]) atomicMin(&sh_next[j], (unsigned)tid);
-    }
-    __syncthreads();
-    if (tid < NQ) {
-        const int j = tid;
-        const float rank = a.q[j] * (float)(n - 1);
-        const float lo_f = floorf(rank), w = rank - lo_f;
-        const unsigned p22 = (sh_bin0[j] << 10) | sh_bin1[j];
-        const unsigned key_lo = (p22 << 10) | sh_bin2[j];
-        const float v_lo = key2f(key_lo);
-        float v_hi = v_lo;
-        if (w != 0.f) {
-            const unsigned mult = h2[j][sh_bin2[j]];
-            if (sh_kk[j] + 1 >= mult) {                    // the element of rank lo + 1 is a larger key
-                const unsigned ab = above[j];
-                if (sh_next[j] != QNONE) v_hi = key2f((p22 << 10) | sh_next[j]);
-                else if (sh_min[j] != QNONE) v_hi = key2f(sh_min[j]);
-                else if (ab != 0u) v_hi = key2f(~ab);
-            }
-        }
-        const float d = v_hi - v_lo;                         // at::lerp: w < 0.5 ? a + w*(b-a) : b - (b-a)*(1-w)
-        a.out[(int64_t)j * a.R + r] = (w < 0.5f) ? v_lo + w * d : v_hi - d * (1.f - w);
-    }
-    __syncthreads();
-    // leave the row's workspace zeroed for the next call (stream order makes it visible)
-    reinterpret_cast<uint4*>(g0)[tid] = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-    for (int j = 0; j < QMAX; ++j) g1[j * QB1 + tid] = 0u;
-    if (tid < QMAX) { ccount[tid] = 0; above[tid] = 0; }
+        for (int j = 0; j < QMAX; ++j)
+            if (j < NQ && hvj[j] != 0 && (unsigned)tid > sh_bin[j]) atomicMin(&sh_next[j], (unsigned)tid);
+        __syncthreads();
+        if (tid < NQ) {
+            const int j = tid;
+            const float rank = a.q[j] * (float)(n - 1);
+            const float lo_f = floorf(rank), w = rank - lo_f;
+            const unsigned key_lo = (pre[j] << 10) | sh_bin[j];
+            const float v_lo = key2f(key_lo);
+            float v_hi = v_lo;
+            if (w != 0.f) {
+                const unsigned mult = g[j * QB1 + sh_bin[j]];
+                if (sh_kk[j] + 1 >= mult) {                // the element of rank lo + 1 is a larger key
+                    const unsigned ab = jobs.above[rt * QMAX + j];
+                    if (sh_next[j] != QNONE) v_hi = key2f((pre[j] << 10) | sh_next[j]);
+                    else if (ab != 0u) v_hi = key2f(~ab);
+                }
+            }
+            const float dlt = v_hi - v_lo;                   // at::lerp: w < 0.5 ? a + w*(b-a) : b - (b-a)*(1-w)
+            a.out[(int64_t)j * a.R + r] = (w < 0.5f) ? v_lo + w * dlt : v_hi - dlt * (1.f - w);
+        }
+        __syncthreads();
+        if (tid < QMAX) jobs.above[rt * QMAX + tid] = 0;
+        if (tid < QSEL) sel[tid] = 0;
+    }
+    // this level's histograms are done: zero them for the next call (stream order makes it visible)
+#pragma unroll
+    for (int j = 0; j < QMAX; ++j) g[j * QB1 + tid] = 0u;
 }
 
 // ---- small rows (N <= QROW_MAX): ONE launch, one workgroup per row through all three levels (round 1 / early round 2).
@@ -665,22 +565,12 @@ static int quant_check(const QuantArgs& a) {
     return CP2_OK;
 }
 
-static int quant_cap(int N) {
-    int cap = N / 16;
-    if (cap < 4096) cap = 4096;
-    if (cap > N) cap = N < 1 ? 1 : N;
-    return (cap + 3) & ~3;
-}
-
 // words (4 bytes) of workspace for the given jobs
 static int64_t quant_ws_words(int njobs, const int* R, const int* N, int NQ) {
-    int64_t rows = 0, cand = 0;
-    for (int j = 0; j < njobs; ++j) {
-        if (R[j] <= 0 || N[j] <= 0) continue;
-        rows += R[j];
-        cand += (int64_t)R[j] * NQ * quant_cap(N[j]);
-    }
-    return rows * QROW_WORDS + cand;
+    int64_t rows = 0;
+    for (int j = 0; j < njobs; ++j)
+        if (R[j] > 0 && N[j] > 0) rows += R[j];
+    return rows * QROW_WORDS;
 }
 
 CP2_API int64_t cp2_quantiles_workspace_bytes(int njobs, const int* R, const int* N, int NQ) {
@@ -709,16 +599,12 @@ static int quant_launch(QuantJobs& jobs, int njobs, void* workspace, int64_t wor
     if (!workspace) return CP2_ERR_NULL;
     if (!cp2_aligned16(workspace)) return CP2_ERR_ALIGN;
     int rows = 0, chunks = 0;
-    int64_t cand = 0;
     int Rs[QJOBS], Ns[QJOBS];
     for (int j = 0; j < njobs; ++j) {
         QuantArgs& a = jobs.job[j];
         int rc = quant_check(a);
         if (rc) return rc;
         a.chunks = cp2_cdiv(a.N, QCHUNK);
-        a.cap = quant_cap(a.N);
-        a.cand_off = cand;
-        cand += (int64_t)a.R * a.NQ * a.cap;
         jobs.first_row[j] = rows;
         jobs.first_chunk[j] = chunks;
         rows += a.R;
@@ -731,17 +617,20 @@ static int quant_launch(QuantJobs& jobs, int njobs, void* workspace, int64_t wor
     unsigned* w = static_cast<unsigned*>(workspace);
     jobs.hist0 = w;
     jobs.hist1 = jobs.hist0 + (int64_t)rows * QB0;
-    jobs.ccount = jobs.hist1 + (int64_t)rows * QMAX * QB1;
-    jobs.above = jobs.ccount + (int64_t)rows * QMAX;
-    jobs.cand = jobs.above + (int64_t)rows * QMAX;
-    // measurement aid: the armed start event rides on K1, the stop event on K3 (elapsed = the three launches)
+    jobs.hist2 = jobs.hist1 + (int64_t)rows * QMAX * QB1;
+    jobs.above = jobs.hist2 + (int64_t)rows * QMAX * QB1;
+    jobs.sel = jobs.above + (int64_t)rows * QMAX;
+    // measurement aid: the armed start event rides on the first launch, the stop event on the last (elapsed = all six)
     const Cp2LaunchEvents ev = cp2_next_events;
     cp2_next_events = Cp2LaunchEvents{};
-    if (ev.start) hipExtLaunchKernelGGL(quantile_hist_kernel, dim3(chunks), dim3(QT1), 0, stream, ev.start, nullptr, 0, jobs);
-    else hipLaunchKernelGGL(quantile_hist_kernel, dim3(chunks), dim3(QT1), 0, stream, jobs);
-    hipLaunchKernelGGL(quantile_compact_kernel, dim3(chunks), dim3(QT1), 0, stream, jobs);
-    if (ev.stop) hipExtLaunchKernelGGL(quantile_final_kernel, dim3(rows), dim3(QT3), 0, stream, nullptr, ev.stop, 0, jobs);
-    else hipLaunchKernelGGL(quantile_final_kernel, dim3(rows), dim3(QT3), 0, stream, jobs);
+    if (ev.start) hipExtLaunchKernelGGL(quantile_hist_kernel<0>, dim3(chunks), dim3(QT1), 0, stream, ev.start, nullptr, 0, jobs);
+    else hipLaunchKernelGGL(quantile_hist_kernel<0>, dim3(chunks), dim3(QT1), 0, stream, jobs);
+    hipLaunchKernelGGL(quantile_select_kernel<0>, dim3(rows), dim3(QT3), 0, stream, jobs);
+    hipLaunchKernelGGL(quantile_hist_kernel<1>, dim3(chunks), dim3(QT1), 0, stream, jobs);
+    hipLaunchKernelGGL(quantile_select_kernel<1>, dim3(rows), dim3(QT3), 0, stream, jobs);
+    hipLaunchKernelGGL(quantile_hist_kernel<2>, dim3(chunks), dim3(QT1), 0, stream, jobs);
+    if (ev.stop) hipExtLaunchKernelGGL(quantile_select_kernel<2>, dim3(rows), dim3(QT3), 0, stream, nullptr, ev.stop, 0, jobs);
+    else hipLaunchKernelGGL(quantile_select_kernel<2>, dim3(rows), dim3(QT3), 0, stream, jobs);
     return cp2_launch_status();
 }
 
@@ -749,7 +638,7 @@ CP2_API int cp2_masked_quantiles(const float* x, int64_t stride_row, int64_t str
                                  const float* mask_a, const float* mask_b, int P, int want, const float* q, int NQ,
                                  float* out, void* workspace, int64_t workspace_bytes, void* stream) {
     QuantJobs jobs{};
-    jobs.job[0] = QuantArgs{x, stride_row, stride_elem, N, mask_a, mask_b, P, want, q, NQ, out, R, 0, 0, 0};
+    jobs.job[0] = QuantArgs{x, stride_row, stride_elem, N, mask_a, mask_b, P, want, q, NQ, out, R, 0};
     return quant_launch(jobs, 1, workspace, workspace_bytes, cp2_stream(stream));
 }
 
@@ -761,6 +650,6 @@ CP2_API int cp2_masked_quantiles_multi(int njobs, const float* const* x, const i
     if (!x || !stride_row || !stride_elem || !R || !N || !mask_a || !mask_b || !P || !want || !out) return CP2_ERR_NULL;
     QuantJobs jobs{};
     for (int j = 0; j < njobs; ++j)
-        jobs.job[j] = QuantArgs{x[j], stride_row[j], stride_elem[j], N[j], mask_a[j], mask_b[j], P[j], want[j], q, NQ, out[j], R[j], 0, 0, 0};
+        jobs.job[j] = QuantArgs{x[j], stride_row[j], stride_elem[j], N[j], mask_a[j], mask_b[j], P[j], want[j], q, NQ, out[j], R[j], 0};
     return quant_launch(jobs, njobs, workspace, workspace_bytes, cp2_stream(stream));
 }

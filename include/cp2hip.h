@@ -194,9 +194,9 @@ int cp2_dense_infonce_bwd(const float* q_dense, const float* k_dense, const floa
 int cp2_masked_quantiles(const float* x, int64_t stride_row, int64_t stride_elem, int R, int N,
                          const float* mask_a, const float* mask_b, int P, int want, const float* q, int NQ,
                          float* out, void* workspace, int64_t workspace_bytes, void* stream);
-/* Up to 4 such problems in one call of three launches (rows cut into 8192-element chunks: first-level histogram,
- * candidate compaction, per-row select; NQ <= 4 quantiles q shared by all jobs).  Every argument of
- * cp2_masked_quantiles becomes a HOST array of njobs entries (device pointers inside).
+/* Up to 4 such problems in one call (NQ <= 4 quantiles q shared by all jobs).  Every argument of cp2_masked_quantiles
+ * becomes a HOST array of njobs entries (device pointers inside).  Rows longer than CP2_QUANTILES_ROW_MAX are cut into
+ * 8192-element chunks: three chunk-parallel histogram passes (12 + 10 + 10 bits) with a per-row select after each.
  * When every job has N <= CP2_QUANTILES_ROW_MAX the call is ONE launch (one workgroup per row through all three
  * levels) and needs no workspace (NULL, 0).  Otherwise:
  * workspace: device memory of cp2_quantiles_workspace_bytes(njobs, R, N, NQ) bytes, 16-byte aligned, ZERO before the

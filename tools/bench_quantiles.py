@@ -6,9 +6,9 @@ dev = 'cuda'
 g = torch.Generator(device=dev).manual_seed(0)
 
 
-def step_shape(B, K, P, iters):
-    lneg = torch.randn(B, K, device=dev, generator=g) * 0.088
-    logits = torch.randn(B, P, P, device=dev, generator=g) * 0.088
+def step_shape(B, K, P, iters, centre=0.0, spread=0.088):
+    lneg = centre + torch.randn(B, K, device=dev, generator=g) * spread
+    logits = centre + torch.randn(B, P, P, device=dev, generator=g) * spread
     ma = (torch.rand(B, P, device=dev, generator=g) > 0.4).float(); mb = (torch.rand(B, P, device=dev, generator=g) > 0.5).float()
     dense = dict(x=logits, stride_row=P * P, stride_elem=1, R=B, N=P * P, mask_a=ma, mask_b=mb)
     for _ in range(iters):                                        # the step's three statistics in one call
@@ -21,4 +21,5 @@ def step_shape(B, K, P, iters):
 
 step_shape(32, 65536, 196, 20)        # BASELINE config 2 (the bench step)
 step_shape(8, 131072, 4096, 5)        # BASELINE config 4: 8 x 4096^2 dense logits (537 MB), K = 131072
+step_shape(8, 131072, 4096, 5, centre=0.87, spread=0.02)   # the same with the narrow band of a freshly initialised encoder
 print("ok")
