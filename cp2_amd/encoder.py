@@ -225,6 +225,19 @@ class Conv2d(nn.Conv2d):
     graph_step = False       # set by engine.TrainStep(use_graph=True): warm-up steps must take the path the capture takes
     cpp_nodes = True         # autograd nodes from the C++ extension when it is built (A/B: False = the Python nodes)
     hip_wgrad_kxk = True     # weight gradient of the k x k layers by cp2_wgrad_conv (A/B: False = MIOpen)
+    kxk_wgrad_max_flops = 32e9   # ... for layers up to this much weight-gradient work in eager steps (see _kxk_wgrad_small)
+
+    def _kxk_wgrad_small(self, x) -> bool:
+        """cp2_wgrad_conv or MIOpen for this layer's weight gradient (eager steps; a captured step always takes
+        cp2_wgrad_conv: MIOpen's split-K kernels are of the zero-fill + atomics kind that failed under replay).
+        Measured per shape (tools/wgrad_conv_vs_miopen.py, MIOpen incl. its fill / cast launches): cp2_wgrad_conv is
+        ahead up to ~30 GFLOP of weight-gradient work (64->64 at 32 x 56^2: 37 vs 42 us; 128->128: 30-38 vs 35-44;
+        512->512 at 32 x 14^2: 93 vs 95), behind above it (256->256 at 8 x 64^2, 39 GFLOP: 103 vs 96 us; 512->512 at
+        8 x 64^2: 350 vs 264; the FCN head at 32 x 14^2: 250 / 273 vs 236 / 262, at 8 x 64^2: 1200 vs 859)."""
+        k, s_, p_, d_ = self.kernel_size[0], self.stride[0], self.padding[0], self.dilation[0]
+        oh = (x.shape[2] + 2 * p_ - d_ * (k - 1) - 1) // s_ + 1
+        ow = (x.shape[3] + 2 * p_ - d_ * (k - 1) - 1) // s_ + 1
+        return 2.0 * x.shape[0] * oh * ow * self.in_channels * self.out_channels * k * k <= Conv2d.kxk_wgrad_max_flops
 
     def forward(self, x):
         w = self.shadow_weight
@@ -260,7 +273,8 @@ class Conv2d(nn.Conv2d):
                     and isinstance(self.padding[0], int) and self.in_channels % 64 == 0 and self.out_channels % 64 == 0
                     and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
                     and self.weight.requires_grad and torch.is_grad_enabled()
-                    and self.weight.is_contiguous(memory_format=torch.channels_last)):
+                    and self.weight.is_contiguous(memory_format=torch.channels_last)
+                    and (Conv2d.graph_step or torch.cuda.is_current_stream_capturing() or self._kxk_wgrad_small(x))):
                 # k x k layers: weight gradient by cp2_wgrad_conv (fp32, deterministic) instead of MIOpen's zero-fill +
                 # atomic split-K kernel + cast, forward / data gradient unchanged (MIOpen)
                 if ext is not None:
