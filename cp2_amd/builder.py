@@ -170,6 +170,26 @@ def densecl_local_positives(q_embed, k_embed, q_local, k_local, ids_q, ids_k, lm
     return pos, best
 
 
+class _CommTimer:
+    """with-block that brackets an exchange step with timing events on the current stream (no-op when `sink` is None)."""
+
+    def __init__(self, sink, name):
+        self.sink, self.name = sink, name
+
+    def __enter__(self):
+        if self.sink is not None:
+            self.t0 = torch.cuda.Event(enable_timing=True)
+            self.t0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.sink is not None:
+            t1 = torch.cuda.Event(enable_timing=True)
+            t1.record()
+            self.sink.setdefault(self.name, []).append((self.t0, t1))
+        return False
+
+
 class MODEL(nn.Module):
     def __init__(self, cfg, rank, dim=128, K=65536, m=0.999, instance_logits_temp=0.2, pretrain_from_scratch=False,
                  include_background=False, lmbd_cp2_dense_loss=0.2, lmbd_pixel_corr_weight=1,
@@ -274,6 +294,8 @@ class MODEL(nn.Module):
         self.key_forward_graph = True    # replay the (gradient-free) key encoder forward from a hipGraph after warm-up
         self._key_graph = None
         self._pending_logs = []          # device scalars waiting for one batched device->host copy
+        self.shuffle_exchange = "all_to_all"   # shuffle-BN rows by all-to-all; "all_gather" = the reference's form
+        self.comm_events = None          # bench.py: {} -> every exchange step records a (start, stop) event pair
         self.sync_logs_every = 0         # 0: only when flush_logs() / on_train_epoch_end() is called
 
     # ------------------------------------------------------------------ parameters as flat buffers
@@ -416,7 +438,8 @@ class MODEL(nn.Module):
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             keys.record_stream(side)
-            ops.enqueue(queue, concat_all_gather(keys), ptr)
+            with self._comm("c4_key_gather_enqueue"):
+                ops.enqueue(queue, concat_all_gather(keys), ptr)
             self._enqueue_done = torch.cuda.Event()
             self._enqueue_done.record(side)
 
@@ -438,21 +461,44 @@ class MODEL(nn.Module):
         self._enqueue(self.queue2, self.queue2_ptr, keys)
 
     # ------------------------------------------------------------------ shuffle-BN
+    def _comm(self, name):
+        """Event pair around one exchange step on the current stream when bench.py asks for it (comm_events = {})."""
+        return _CommTimer(self.comm_events, name)
+
     @torch.no_grad()
     def _batch_shuffle_ddp(self, x, idx_shuffle=None):
-        x_gather = concat_all_gather(x.contiguous())
+        """Rows of the permuted global batch this rank's key encoder takes (reference builder.py:609-630) and what
+        _batch_unshuffle_ddp needs to undo it.  shuffle_exchange = "all_to_all" (default): only the rows this rank keeps
+        travel (dist.ShufflePlan), the permutation is drawn on every host from a generator seeded once by rank 0;
+        "all_gather": the reference's form -- gather everything, broadcast the permutation, keep a slice."""
+        x = x.contiguous()
+        if x.is_cuda:
+            x.record_stream(torch.cuda.current_stream())      # may be read here on the side stream after its owner drops it
         w = cdist.world_size()
-        if idx_shuffle is None:
-            idx_shuffle = cdist.make_shuffle_index(x_gather.shape[0], x.device)
-        idx_unshuffle = torch.argsort(idx_shuffle)
-        taken = ops.gather_rows(x_gather, cdist.shuffle_rows_for_rank(idx_shuffle, cdist.rank(), w).contiguous())
+        if cdist.multi() and self.shuffle_exchange == "all_to_all":
+            n_all = x.shape[0] * w
+            host = idx_shuffle.cpu() if idx_shuffle is not None else cdist.shared_permutation(n_all, x.device)
+            plan = cdist.ShufflePlan(host, cdist.rank(), w)
+            with self._comm("c1_image_exchange"):
+                taken = cdist.exchange_rows(x, plan, take=ops.gather_rows)
+            return taken, plan
+        with self._comm("c1_image_exchange"):
+            x_gather = concat_all_gather(x)
+            if idx_shuffle is None:
+                idx_shuffle = cdist.make_shuffle_index(x_gather.shape[0], x.device)
+            idx_unshuffle = torch.argsort(idx_shuffle)
+            taken = ops.gather_rows(x_gather, cdist.shuffle_rows_for_rank(idx_shuffle, cdist.rank(), w).contiguous())
         return taken, idx_unshuffle
 
     @torch.no_grad()
     def _batch_unshuffle_ddp(self, x, idx_unshuffle):
-        w = cdist.world_size()
-        x_gather = concat_all_gather(x.float().contiguous())
-        return ops.gather_rows(x_gather, idx_unshuffle.view(w, -1)[cdist.rank()].contiguous())
+        """Undo _batch_shuffle_ddp on the key encoder's outputs (reference builder.py:632-649)."""
+        x = x.float().contiguous()
+        with self._comm("c3_key_unshuffle"):
+            if isinstance(idx_unshuffle, cdist.ShufflePlan):
+                return cdist.exchange_rows(x, idx_unshuffle, backward=True, take=ops.gather_rows)
+            w = cdist.world_size()
+            return ops.gather_rows(concat_all_gather(x), idx_unshuffle.view(w, -1)[cdist.rank()].contiguous())
 
     # ------------------------------------------------------------------ dispatch
     def forward(self, **kwargs):
@@ -521,7 +567,8 @@ class MODEL(nn.Module):
                 k = self._batch_unshuffle_ddp(self._encode_key(img_b), idx_unshuffle)
         q = self._encode(self.encoder_q, img_a).float()                          # queries: b x C x h x w
         if side is not cur:
-            cur.wait_stream(side)
+            with self._comm("key_branch_wait_exposed"):       # main stream idle until EMA + image exchange are done
+                cur.wait_stream(side)
         if k is None:
             with torch.no_grad():
                 if side is not cur:

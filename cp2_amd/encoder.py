@@ -222,14 +222,12 @@ class Conv2d(nn.Conv2d):
 
     shadow_weight = None
     gemm_1x1 = True          # class-wide switch (A/B)
-    graph_step = False       # set by engine.TrainStep(use_graph=True): warm-up steps must take the path the capture takes
     cpp_nodes = True         # autograd nodes from the C++ extension when it is built (A/B: False = the Python nodes)
     hip_wgrad_kxk = True     # weight gradient of the k x k layers by cp2_wgrad_conv (A/B: False = MIOpen)
     kxk_wgrad_max_flops = 32e9   # ... for layers up to this much weight-gradient work in eager steps (see _kxk_wgrad_small)
 
     def _kxk_wgrad_small(self, x) -> bool:
-        """cp2_wgrad_conv or MIOpen for this layer's weight gradient (eager steps; a captured step always takes
-        cp2_wgrad_conv: MIOpen's split-K kernels are of the zero-fill + atomics kind that failed under replay).
+        """cp2_wgrad_conv or MIOpen for this layer's weight gradient.
         Measured per shape (tools/wgrad_conv_vs_miopen.py, MIOpen incl. its fill / cast launches): cp2_wgrad_conv is
         ahead up to ~30 GFLOP of weight-gradient work (64->64 at 32 x 56^2: 37 vs 42 us; 128->128: 30-38 vs 35-44;
         512->512 at 32 x 14^2: 93 vs 95), behind above it (256->256 at 8 x 64^2, 39 GFLOP: 103 vs 96 us; 512->512 at
@@ -244,16 +242,6 @@ class Conv2d(nn.Conv2d):
         if w is not None and x.dtype == torch.bfloat16:
             ext = _cext.load() if Conv2d.cpp_nodes else None
             stride1 = self.stride == (1, 1)
-            if (not stride1 and self.kernel_size == (1, 1) and self.padding == (0, 0) and self.groups == 1 and x.dim() == 4
-                    and (Conv2d.graph_step or torch.cuda.is_current_stream_capturing())
-                    and torch.is_grad_enabled() and self.weight.requires_grad):
-                # A strided 1x1 convolution (the ResNet down-sample branches) is the stride-1 one on the sub-sampled
-                # input.  Used when the step is captured into a hipGraph: every 1x1 weight gradient then comes from
-                # cp2_wgrad1x1 and none from MIOpen's zero-fill + atomic-add solvers (ConvHipImplicitGemmGroupWrwXdlops,
-                # ConvAsmImplicitGemmGTCDynamicWrwXdlopsNHWC), whose results went non-finite from the second replay on
-                # (tools/graph_fault_probe.py).
-                x = x[:, :, ::self.stride[0], ::self.stride[1]].contiguous(memory_format=torch.channels_last)
-                stride1 = True
             if (Conv2d.gemm_1x1 and self.kernel_size == (1, 1) and stride1 and self.padding == (0, 0)
                     and self.groups == 1 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
                 m, ci, co = x.shape[0] * x.shape[2] * x.shape[3], self.in_channels, self.out_channels
@@ -264,17 +252,15 @@ class Conv2d(nn.Conv2d):
                 elif ext is not None:
                     # C++ node: GEMM forward / data gradient where faster, weight gradient by cp2_wgrad1x1 (fp32)
                     return ext.conv1x1(x, self.weight, w, self.bias, mm_fwd, ci >= 128, _Conv1x1Fn.hip_wgrad)
-                elif Conv2d.graph_step or torch.cuda.is_current_stream_capturing():
-                    # the Python node costs ~0.1 ms of host time per layer and step: worth it only when the step is
-                    # being captured into a hipGraph (host time is then paid once)
-                    return _Conv1x1Fn.apply(x, self.weight, w, self.bias, mm_fwd, ci >= 128)
+                # without the C++ extension the layer stays on MIOpen: the Python twin of the node (_Conv1x1Fn) costs
+                # ~0.1 ms of host time per layer and step, which makes the eager step host-bound
             if (Conv2d.hip_wgrad_kxk and self.kernel_size[0] == self.kernel_size[1] and self.kernel_size[0] > 1 and self.groups == 1
                     and self.stride[0] == self.stride[1] and self.padding[0] == self.padding[1] and self.dilation[0] == self.dilation[1]
                     and isinstance(self.padding[0], int) and self.in_channels % 64 == 0 and self.out_channels % 64 == 0
                     and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
                     and self.weight.requires_grad and torch.is_grad_enabled()
                     and self.weight.is_contiguous(memory_format=torch.channels_last)
-                    and (Conv2d.graph_step or torch.cuda.is_current_stream_capturing() or self._kxk_wgrad_small(x))):
+                    and self._kxk_wgrad_small(x)):
                 # k x k layers: weight gradient by cp2_wgrad_conv (fp32, deterministic) instead of MIOpen's zero-fill +
                 # atomic split-K kernel + cast, forward / data gradient unchanged (MIOpen)
                 if ext is not None:
@@ -283,8 +269,6 @@ class Conv2d(nn.Conv2d):
             if self.weight.requires_grad and torch.is_grad_enabled():
                 w = ext.shadow_weight(self.weight, w) if ext is not None else _ShadowWeightFn.apply(self.weight, w)
             b = self.bias.to(torch.bfloat16) if self.bias is not None else None
-            if stride1 and self.stride != (1, 1):               # sub-sampled above, but the GEMM route did not take it
-                return F.conv2d(x, w, b)
             return self._conv_forward(x, w, b)
         return super().forward(x)
 

@@ -102,7 +102,6 @@ def get_args(argv=None):
     p.add_argument("--steps_per_epoch", default=100, type=int, help="with --synthetic: steps per epoch")
     p.add_argument("--amp", default="bf16", choices=["none", "bf16"], help="encoder autocast dtype")
     p.add_argument("--no_channels_last", action="store_true")
-    p.add_argument("--graph", action="store_true", help="capture the whole step in a hipGraph (single GPU)")
     # fmt: on
     args = p.parse_args(argv)
     args.pretrain_type = PretrainType[args.pretrain_type]
@@ -122,8 +121,8 @@ def get_args(argv=None):
 
 
 def make_optimizer(params, args, device, capturable: bool, model=None):
-    """SGD(momentum, wd) / AdamW as reference main.py:467-477.  For hipGraph capture the learning rate is
-    a device tensor, so the LR schedule needs no re-capture.  With `model` (a builder.MODEL on the GPU) the SGD step is
+    """SGD(momentum, wd) / AdamW as reference main.py:467-477.  capturable: keep the learning rate in a device tensor
+    (a caller that captures the update into a hipGraph of its own then needs no re-capture per LR change).  With `model` (a builder.MODEL on the GPU) the SGD step is
     cp2_amd.optim.FlatSGD: the same update as torch.optim.SGD, bit for bit, in one HIP launch on the flat buffer."""
     lr = torch.tensor(float(args.lr), device=device) if capturable else args.lr
     if args.optim == "adamw":
@@ -188,7 +187,6 @@ def main_worker(rank, args):
     if not args.no_channels_last:
         model.encoder_q.to(memory_format=torch.channels_last)
         model.encoder_k.to(memory_format=torch.channels_last)
-    use_graph = args.graph and world == 1
     wrapped = model
     if world > 1:
         # queue / BN buffers are updated identically on every rank, so the per-forward buffer
@@ -197,17 +195,13 @@ def main_worker(rank, args):
         # and the unselected neck heads for DENSECL / PROPOSED_V2), so no unused-parameter search either.
         wrapped = DistributedDataParallel(model, device_ids=[local], output_device=local, broadcast_buffers=False,
                                           gradient_as_bucket_view=True)
-    optimizer = make_optimizer([p for p in model.parameters()], args, device, capturable=use_graph, model=model)
+    optimizer = make_optimizer([p for p in model.parameters()], args, device, capturable=False, model=model)
     if args.resume and os.path.isfile(args.resume):
         ck = torch.load(args.resume, map_location=device)
         args.start_epoch = ck["epoch"]
         wrapped.load_state_dict(ck["state_dict"]) if world > 1 else model.load_state_dict(
             {k.replace("module.", "", 1): v for k, v in ck["state_dict"].items()})
         optimizer.load_state_dict(ck["optimizer"])
-        if use_graph:      # a checkpoint written by an eager run holds the learning rate as a float: the captured
-            for g in optimizer.param_groups:                   # update must read it from device memory (LR schedule)
-                if not isinstance(g["lr"], torch.Tensor):
-                    g["lr"] = torch.tensor(float(g["lr"]), device=device)
     per_gpu = args.batch_size // world
     dataset = None
     if args.tensor_dataset:
@@ -225,7 +219,7 @@ def main_worker(rank, args):
     else:
         raise NotImplementedError("give --tensor_dataset FILE (images resident in HBM, augmented on the device) or "
                                   "--synthetic; decoding image folders (reference datasets/, PIL / cv2) is outside the hot path")
-    runner = TrainStep(wrapped, optimizer, use_graph=use_graph)
+    runner = TrainStep(wrapped, optimizer)
     step = 0
     for epoch in range(args.start_epoch, args.epochs):
         lr = args.lr if args.remove_lr_scheduler else adjust_learning_rate(optimizer, epoch, args)

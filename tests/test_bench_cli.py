@@ -1,0 +1,88 @@
+"""bench.py as the driver runs it.  CPU part: `python bench.py --gpus N` without a launcher starts its own N ranks
+(reference main.py:732 spawns its ranks itself) before anything touches a GPU, hands them the launcher environment, and
+reports a failing rank through its exit code.  GPU part: the N = 1 line and a two-rank rehearsal on one device (gloo)
+carry the fields the contract names, including the per-exchange `comm` breakdown."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--config", os.path.join(ROOT, "configs", "config_pretrain_r18.py"), "--img", "64", "--queue", "1024",
+         "--batch-per-gpu", "4", "--steps", "3", "--warmup", "4"]
+
+
+def _run(argv, env=None, timeout=500):
+    e = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, cwd=ROOT, env=e, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_self_launch_starts_every_rank_and_reports_a_failing_one():
+    """On a box without a GPU every rank stops at bench.py's own "needs a GPU" assertion: that message must come from
+    ranks the parent started itself (two of them, each with its RANK), and the parent must exit non-zero."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check (on a GPU box the GPU tests below run the real thing)")
+    res = _run(["--gpus", "2", "--no-cpu-baseline"] + SMALL, env={"CP2_BENCH_ECHO_RANK": "1"}, timeout=240)
+    assert res.returncode != 0
+    assert res.stderr.count("bench.py needs a GPU") >= 1
+    assert "exited with code" in res.stderr and "stopping the other ranks" in res.stderr
+    assert res.stdout.strip() == ""                       # no partial JSON line
+
+
+def test_world_size_mismatch_is_refused():
+    res = _run(["--gpus", "2"], env={"RANK": "0", "WORLD_SIZE": "4", "LOCAL_RANK": "0"}, timeout=120)
+    assert res.returncode != 0 and "WORLD_SIZE=4 but --gpus 2" in res.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_bench_n1_line_has_the_contract_fields():
+    res = _run(["--gpus", "1", "--cpu-steps", "1", "--cpu-warmup", "0", "--cpu-batch", "2"] + SMALL)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1                                 # ONE JSON line on stdout
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["value"] > 0 and "comm" not in out
+    r = out["roofline"]
+    assert r["bound"] == "hbm" and "sgd_flat_kernel" in r["kernel"] and r["bytes_per_slot_algorithmic"] == 20
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["bytes_fused"] >= r["bytes_algorithmic"]
+    ema = out["roofline_kernels"][0]
+    assert "ema_flat_kernel" in ema["kernel"] and ema["bytes_per_slot_algorithmic"] == 12
+    c = out["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["threads"] >= 1 and c["value"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("exchange", ["all_to_all", "all_gather"])
+def test_bench_two_ranks_one_device_without_a_launcher(exchange):
+    """`python bench.py --gpus 2 --one-device --backend gloo`: no launcher, two ranks on cuda:0 (RCCL refuses that, so
+    gloo), whole-job value, comm breakdown with every exchange step timed."""
+    res = _run(["--gpus", "2", "--one-device", "--backend", "gloo", "--shuffle-exchange", exchange, "--nosync-steps", "2"] + SMALL)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp2"
+    assert "cpu_baseline" not in out                       # rank 0 at N = 1 only
+    assert abs(out["value"] - 8 / (out["ms_per_step"] * 1e-3)) < 0.02 * out["value"]     # whole-job images/s
+    c = out["comm"]
+    assert c["backend"] == "gloo" and c["rccl_ranks"] == 2 and c["launcher"] == "self" and c["shuffle_exchange"] == exchange
+    ms = c["ms_per_step"]
+    for k in ("c1_image_exchange", "c3_key_unshuffle", "c4_key_gather_enqueue", "key_branch_wait_exposed",
+              "step_without_grad_allreduce", "ddp_allreduce_exposed"):
+        assert ms[k] is not None, k
+    assert ms["c1_image_exchange"] > 0 and ms["c3_key_unshuffle"] > 0 and ms["c4_key_gather_enqueue"] > 0
+    by = c["bytes_received_per_rank_per_step"]
+    row = 3 * 64 * 64 * 4
+    assert by["c1_image_exchange"] == (2 * row if exchange == "all_to_all" else 4 * row)

@@ -47,12 +47,26 @@ def _worker(rank, world, port, out_dir):
         restored = enc_all[rows]
         assert torch.equal(restored, x * 2.0 + 1.0)
         assert torch.equal(restored, O.unshuffle_take(enc_all, idx, rank, world))
+        # the same shuffle / un-shuffle by all-to-all (only the rows a rank keeps travel): equal to the all-gather form
+        # for the broadcast permutation and for permutations drawn from the shared host generator
+        for it in range(6):
+            perm = idx if it == 0 else cdist.shared_permutation(world * b)
+            chk = perm.clone()
+            dist.broadcast(chk, src=0)
+            assert torch.equal(perm, chk)                   # every rank drew the same permutation, no per-step broadcast
+            plan = cdist.ShufflePlan(perm, rank, world)
+            assert sum(plan.send_counts) == b == sum(plan.recv_counts)
+            got = cdist.exchange_rows(x, plan)
+            assert torch.equal(got, O.shuffle_take(g, perm, rank, world))
+            back = cdist.exchange_rows(got * 2.0 + 1.0, plan, backward=True)
+            assert torch.equal(back, x * 2.0 + 1.0)
+            assert plan.bytes_received(16) == 16 * (b - plan.recv_counts[rank])
         # enqueue: every rank appends ALL ranks' keys in rank order -> replicas of the queue stay identical
-        K, C = 8, 4
+        K, C = 16, 4
         queue = torch.zeros(C, K)
-        ptr = 5                                            # crosses the wrap boundary with 6 keys
+        ptr = 13                                           # crosses the wrap boundary
         queue, ptr = O.dequeue_and_enqueue(queue, ptr, cdist.concat_all_gather(x))
-        assert ptr == (5 + world * b) % K
+        assert ptr == (13 + world * b) % K
         torch.save(queue, os.path.join(out_dir, f"q{rank}.pt"))
         dist.barrier()
     finally:
@@ -60,13 +74,13 @@ def _worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(120)
-def test_world2_gloo_collectives(tmp_path):
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_world_n_gloo_collectives(tmp_path, world):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     q0, q1 = torch.load(tmp_path / "q0.pt"), torch.load(tmp_path / "q1.pt")
     assert torch.equal(q0, q1)
     want = torch.cat([torch.arange(12, dtype=torch.float32).reshape(3, 4) + 1000 * r for r in range(world)])
-    cols = [(5 + i) % 8 for i in range(6)]
+    cols = [(13 + i) % 16 for i in range(world * 3)]
     assert torch.equal(q0[:, cols], want.t())
 
 
@@ -76,3 +90,7 @@ def test_single_process_helpers_without_process_group():
     assert cdist.concat_all_gather(x) is x
     idx = cdist.make_shuffle_index(8, "cpu", generator=torch.Generator().manual_seed(1))
     assert sorted(idx.tolist()) == list(range(8))
+    # a one-rank plan is the identity exchange: everything stays local
+    plan = cdist.ShufflePlan(idx, 0, 1)
+    assert plan.send_counts == [8] and plan.recv_counts == [8] and plan.bytes_received(4) == 0
+    assert torch.equal(plan.send_rows[plan.place], idx)

@@ -44,6 +44,26 @@ def _worker(rank, world, port, out_dir, mode="torch-sgd"):
                               amp_dtype=torch.bfloat16, channels_last=True, **extra).to(dev).train()
         model.encoder_q.to(memory_format=torch.channels_last)
         model.encoder_k.to(memory_format=torch.channels_last)
+        if mode == "exchange-equality":
+            # shuffle-BN by all-to-all (only the rows a rank keeps travel) == the reference's all-gather form, bit for bit,
+            # for the images going in and the keys coming back (gather_rows kernels + the collectives, two ranks)
+            from cp2_amd import dist as cdist
+            for it in range(4):
+                x = torch.randn(6, 3, 32, 32, device=dev, generator=torch.Generator(dev).manual_seed(10 * rank + it))
+                perm = cdist.make_shuffle_index(12, dev)                       # rank 0's permutation on every rank
+                model.shuffle_exchange = "all_to_all"
+                a, plan = model._batch_shuffle_ddp(x, perm)
+                model.shuffle_exchange = "all_gather"
+                g, idx_un = model._batch_shuffle_ddp(x, perm)
+                assert isinstance(plan, cdist.ShufflePlan) and torch.equal(a, g)
+                k = a * 3.0 - 1.0
+                assert torch.equal(model._batch_unshuffle_ddp(k, plan), model._batch_unshuffle_ddp(k, idx_un))
+                assert torch.equal(model._batch_unshuffle_ddp(k, plan), x * 3.0 - 1.0)
+            torch.save({"ok": True}, os.path.join(out_dir, f"r{rank}.pt"))
+            dist.barrier()
+            return
+        if mode == "flat-gather-allgather":
+            model.shuffle_exchange = "all_gather"
         ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], output_device=0, broadcast_buffers=False,
                                                         gradient_as_bucket_view=True)
         steps = 3
@@ -52,7 +72,7 @@ def _worker(rank, world, port, out_dir, mode="torch-sgd"):
         else:        # the bench / main.py configuration: FlatSGD, enough steps for the key-forward hipGraph to be replayed
             from cp2_amd.optim import FlatSGD
             opt = FlatSGD(ddp, 0.01, momentum=0.9, weight_decay=1e-4)
-            model.overlap_key_branch = {"flat-gather": None, "flat-branch": True}[mode]
+            model.overlap_key_branch = {"flat-gather": None, "flat-gather-allgather": None, "flat-branch": True}[mode]
             steps = 6
         b = 6
         for step in range(steps):
@@ -76,7 +96,7 @@ def _worker(rank, world, port, out_dir, mode="torch-sgd"):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("mode", ["torch-sgd", "flat-gather", "flat-branch", "densecl", "densecl-v2"])
+@pytest.mark.parametrize("mode", ["torch-sgd", "flat-gather", "flat-gather-allgather", "flat-branch", "densecl", "densecl-v2"])
 def test_two_ranks_one_device_gloo(tmp_path, mode):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), mode), nprocs=world, join=True)
@@ -85,3 +105,9 @@ def test_two_ranks_one_device_gloo(tmp_path, mode):
     assert torch.equal(r0["queue"], r1["queue"])                  # identical enqueue on every rank, in rank order
     assert torch.equal(r0["grad"], r1["grad"]) and float(r0["grad"].abs().max()) > 0   # DDP-averaged gradients
     assert torch.equal(r0["w"], r1["w"]) and torch.equal(r0["k"], r1["k"])             # replicas stay in lock-step
+
+
+@pytest.mark.timeout(300)
+def test_shuffle_by_all_to_all_equals_all_gather_form(tmp_path):
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), "exchange-equality"), nprocs=2, join=True)
+    assert torch.load(tmp_path / "r0.pt")["ok"] and torch.load(tmp_path / "r1.pt")["ok"]

@@ -1,5 +1,5 @@
 """GPU: the RCCL ("nccl") code path with the one rank a 1-GPU box allows -- the very calls the 8-GPU run makes
-(dist.concat_all_gather -> all_gather_into_tensor, index broadcast, DDP buckets with gradient_as_bucket_view feeding
+(dist.concat_all_gather -> all_gather_into_tensor, the shuffle-BN all_to_all_single, index / seed broadcast, DDP buckets with gradient_as_bucket_view feeding
 FlatSGD), so the driver's multi-GPU bench does not meet them for the first time.  World size 1 makes every collective
 an identity; what is checked is that the calls are accepted by this torch / RCCL build on device tensors, run on the
 side stream, and leave the same state as the single-process path."""
@@ -43,6 +43,13 @@ def _worker(rank, port, out_dir):
         assert torch.equal(out, x)
         idx = cdist.make_shuffle_index(6, dev)               # randperm + broadcast from rank 0
         assert sorted(idx.tolist()) == list(range(6))
+        # the shuffle-BN exchange as the multi-GPU run makes it: seed broadcast once, all_to_all_single with row counts
+        from cp2_amd import ops
+        perm = cdist.shared_permutation(6, dev)
+        plan = cdist.ShufflePlan(perm, 0, 1)
+        y = cdist.exchange_rows(x, plan, take=ops.gather_rows)
+        assert torch.equal(y, x[perm.to(dev)])
+        assert torch.equal(cdist.exchange_rows(y, plan, backward=True, take=ops.gather_rows), x)
         torch.manual_seed(0)
         cfg = Config.fromfile(os.path.join(ROOT, "configs", "config_pretrain_r18.py"))
         model = builder.MODEL(cfg, rank=0, K=256, pretrain_from_scratch=True, pretrain_type=PretrainType.CP2, device=dev,

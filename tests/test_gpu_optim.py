@@ -130,7 +130,7 @@ def test_training_step_with_flat_sgd_matches_torch_sgd_step():
         m.encoder_k.to(memory_format=torch.channels_last)
         opt = FlatSGD(m, 0.03, momentum=0.9, weight_decay=1e-4) if use_flat else \
             torch.optim.SGD([p for p in m.parameters() if p.requires_grad], 0.03, momentum=0.9, weight_decay=1e-4)
-        run = TrainStep(m, opt, use_graph=False)
+        run = TrainStep(m, opt)
         torch.manual_seed(7)
         losses.append([float(run(synthetic.make_batch(8, 64, 64, DEV, seed=i))) for i in range(4)])
     # same maths, different kernels: the FlatSGD model reads bf16 weight images and sends its 1x1 layers through

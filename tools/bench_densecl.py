@@ -30,7 +30,7 @@ class A:
 
 
 opt = make_optimizer(list(model.parameters()), A, dev, capturable=False, model=model)
-runner = TrainStep(model, opt, use_graph=False)
+runner = TrainStep(model, opt)
 batches = [synthetic.make_batch(32, 224, 224, dev, seed=i) for i in range(4)]
 for i in range(8):
     runner(batches[i % 4])
