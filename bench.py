@@ -167,6 +167,12 @@ def main():
         # no launcher: start the ranks ourselves, BEFORE anything touches the GPU (never fork / exec after HIP is up)
         raise SystemExit(launch_ranks(args.gpus))
 
+    # stdout carries ONE line, the JSON: everything else that writes to file descriptor 1 (the constructor's prints, but also
+    # C++ code such as gloo's "[Gloo] Rank 0 is connected ..." banner) is sent to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -391,7 +397,8 @@ def main():
                                          f"same model) after {args.cpu_warmup} warm-up steps, fp32, {secs:.1f} s",
                                "split_ms_per_step": time_cpu_baseline.last_split_ms}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 

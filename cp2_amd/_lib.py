@@ -39,7 +39,12 @@ SIGNATURES = {
     "cp2_dense_num_splits": [c_int, c_int],
     "cp2_dense_infonce_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, _P, _P, _P, _P,
                               _P, _P, _P, _P, _P, _P, c_int, c_float, _P, c_int, c_int, c_int, _P],
-    "cp2_crop_resize_flip": [_P, c_int, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
+    "cp2_crop_resize_flip": [_P, c_int, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P],
+    "cp2_pil_resize_ksize": [c_int, c_int, c_int, c_int],
+    "cp2_pil_resize_workspace_bytes": [c_int, c_int, c_int, c_int, c_int],
+    "cp2_pil_resize_crop": [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, _P, c_int64, _P],
+    "cp2_color_ops": [_P, _P, _P, c_int, c_int, c_int, _P],
+    "cp2_blur_to_tensor": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "cp2_erase_rect": [_P, _P, c_int, c_int, c_int, _P],
     "cp2_sgd_flat": [_P, _P, _P, _P, c_int, _P, _P, c_float, _P, c_float, c_float, _P],
     "cp2_bf16_image": [_P, _P, c_int64, _P],
@@ -61,7 +66,7 @@ SIGNATURES = {
     "cp2_dense_infonce_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, _P, _P, c_float,
                               _P, _P, c_int, c_float, _P, c_int, c_int, c_int, _P],
 }
-_RESTYPE = {"cp2_error_string": c_char_p, "cp2_quantiles_workspace_bytes": c_int64}
+_RESTYPE = {"cp2_error_string": c_char_p, "cp2_quantiles_workspace_bytes": c_int64, "cp2_pil_resize_workspace_bytes": c_int64}
 
 _lib = None
 

@@ -7,9 +7,16 @@ HBM, with the random parameters drawn on the host the way the reference's transf
     loader.py:39-43,66-73  pixel ids at pixel_ids_stride       id_stride argument of the kernel
     main.py:204-225   RandomResizedCrop, flip, RandomErasing   rrc_params(), erase_params() -> crop_resize_flip + erase_rect
     main.py:263-289   three DistributedSamplers (seeds 0/1024/2048)   EpochSampler
+    main.py:212-216, loader.py:121-152  ColorJitter(0.4,0.4,0.4,0.1) p=0.8, grayscale p=0.2, GaussianBlur([0.1,2]) p=0.5
+                                                            jitter_table() / blur_table() -> ops.color_ops, ops.blur_to_tensor
 
-The photometric transforms of the reference (ColorJitter, ToGray, GaussianBlur: image values only, no effect on the
-input contract or on the id maps) are not part of this module.
+Pixel values.  Background views follow torchvision's PIL code path in Pillow's own integer / float arithmetic
+(csrc/photometric.hip; pinned against Pillow by tests/golden/make_augment_goldens.py): crop + antialiased bilinear resize,
+the four colour adjustments in their drawn order, grayscale, Gaussian blur, flip, ToTensor, RandomErasing.  Foreground
+views are cv2 / albumentations in the reference (loader.py:93-109), neither installed nor pinned: their crop is resampled
+with cv2.resize's geometry (half-pixel centres, no antialiasing) in fp32 and rounded to uint8 -- PARITY-UNPINNED -- and
+then go through the same Pillow-arithmetic colour stages (albumentations' own LUT arithmetic is unpinned as well) and
+Pillow's Gaussian blur, which IS what the reference calls for them (loader.py:136-152).
 """
 from __future__ import annotations
 
@@ -66,6 +73,57 @@ def erase_params(rng: np.random.Generator, n: int, h: int, w: int, scale=(0.5, 0
     return np.stack([top, left, hh, ww], 1).astype(np.int32)
 
 
+def jitter_table(rng: np.random.Generator, n: int, brightness=0.4, contrast=0.4, saturation=0.4, hue=0.1, p: float = 0.8,
+                 p_gray: float = 0.2) -> np.ndarray:
+    """RandomApply([ColorJitter(b, c, s, h)], p) + RandomGrayscale(p_gray) parameters for n samples (torchvision
+    ColorJitter.get_params: a random order of the four adjustments, factors ~ U(1-x, 1+x), hue ~ U(-h, h)), as the int32
+    [n, 12] rows of cp2_color_ops: order[4] (-1 = not applied), float bits of the three factors, uint8(hue * 255), gray."""
+    t = np.zeros((n, 12), dtype=np.int32)
+    apply = rng.random(n) < p
+    order = rng.permuted(np.tile(np.arange(4, dtype=np.int32), (n, 1)), axis=1)
+    t[:, 0:4] = np.where(apply[:, None], order, -1)
+    f = np.stack([rng.uniform(1 - x, 1 + x, n) for x in (brightness, contrast, saturation)], 1).astype(np.float32)
+    t[:, 4:7] = f.view(np.int32)
+    t[:, 7] = hue_shift_u8(rng.uniform(-hue, hue, n))
+    t[:, 8] = rng.random(n) < p_gray
+    return t
+
+
+def hue_shift_u8(hue_factor) -> np.ndarray:
+    """np.uint8(hue_factor * 255) as torchvision's adjust_hue computes it: truncation toward zero, then wrap-around."""
+    return (np.trunc(np.asarray(hue_factor, dtype=np.float64) * 255).astype(np.int64) % 256).astype(np.int32)
+
+
+def gaussian_box(sigma: float):
+    """Pillow's box approximation of GaussianBlur(sigma) (BoxBlur.c _gaussian_blur_radius with 3 passes, then
+    ImagingHorizontalBoxBlur's weights), in the float32 arithmetic of the C source: (integer radius, ww, fw)."""
+    f32 = np.float32
+    sigma2 = f32(f32(f32(sigma) * f32(sigma)) / f32(3))
+    box_len = f32(math.sqrt(12.0 * float(sigma2) + 1.0))
+    l = f32(math.floor((float(box_len) - 1.0) / 2.0))
+    a = f32(f32(f32(2) * l + f32(1)) * f32(f32(l * f32(l + f32(1))) - f32(f32(3) * sigma2)))
+    a = f32(a / f32(f32(6) * f32(sigma2 - f32(f32(l + f32(1)) * f32(l + f32(1))))))
+    radius = f32(l + a)
+    r = int(radius)
+    ww = int(f32(1 << 24) / f32(f32(radius * f32(2)) + f32(1)))
+    fw = ((1 << 24) - (r * 2 + 1) * ww) // 2
+    return r, ww, fw
+
+
+def blur_table(rng: np.random.Generator, n: int, sigma=(0.1, 2.0), p: float = 0.5):
+    """RandomApply([GaussianBlur(sigma)], p) for n samples: int32 [n, 4] rows of cp2_blur_to_tensor (on, r, ww, fw) and
+    the largest integer radius among them."""
+    t = np.zeros((n, 4), dtype=np.int32)
+    on = rng.random(n) < p
+    sig = rng.uniform(sigma[0], sigma[1], n)
+    rmax = 0
+    for i in np.nonzero(on)[0]:
+        r, ww, fw = gaussian_box(float(sig[i]))
+        t[i] = (1, r, ww, fw)
+        rmax = max(rmax, r)
+    return t, rmax
+
+
 def crop_table(src_index: np.ndarray, boxes: np.ndarray, flips: np.ndarray) -> np.ndarray:
     """int32 [n, 8] parameter rows of cp2_crop_resize_flip."""
     t = np.zeros((len(src_index), 8), dtype=np.int32)
@@ -112,23 +170,48 @@ class DeviceDataset:
 
 def make_step_batch(ds: DeviceDataset, fg_idx: np.ndarray, bg0_idx: np.ndarray, bg1_idx: np.ndarray, h: int, w: int,
                     rng: np.random.Generator, foreground_min: float = 0.5, foreground_max: float = 0.8,
-                    id_stride: int = 1, use_regions: bool = True) -> Dict[str, torch.Tensor]:
-    """One training batch with the keyword set of MODEL.forward (main.py:616-628), every tensor made on the device."""
+                    id_stride: int = 1, use_regions: bool = True, photometric: Optional[bool] = None) -> Dict[str, torch.Tensor]:
+    """One training batch with the keyword set of MODEL.forward (main.py:616-628), every tensor made on the device.
+    photometric (default: on for a uint8 dataset): ColorJitter / grayscale / GaussianBlur as the reference's loaders
+    apply them to every view; False = geometry only (crop, flip, erase) in fp32."""
     dev = ds.images.device
     n, hs, ws = len(fg_idx), ds.images.shape[2], ds.images.shape[3]
+    if photometric is None:
+        photometric = ds.images.dtype == torch.uint8
+    if photometric and ds.images.dtype != torch.uint8:
+        raise ValueError("photometric augmentation works on uint8 images (the reference's PIL / cv2 images are uint8)")
     out = {}
     tabs = []
     for idx in (fg_idx, fg_idx, bg0_idx, bg1_idx):            # query view, key view (same images), two backgrounds
         tabs.append(crop_table(idx, rrc_params(rng, n, hs, ws), rng.random(n) < 0.5))
     rects = np.concatenate([erase_params(rng, n, h, w, (foreground_min, foreground_max)) for _ in range(2)])
-    table = torch.from_numpy(np.concatenate(tabs)).to(dev, non_blocking=True)        # one H2D copy per step
-    rects_d = torch.from_numpy(rects).to(dev, non_blocking=True)
     reg = ds.region_ids if use_regions else None
-    fg = ops.crop_resize_flip(ds.images, reg, table[: 2 * n], h, w, id_stride, want_ids=True)
-    bg = ops.crop_resize_flip(ds.images, None, table[2 * n:], h, w, 1, want_ids=False)
-    ops.erase_rect(bg[0], rects_d)
-    out["img_a"], out["img_b"] = fg[0][:n], fg[0][n:]
+    if not photometric:
+        table = torch.from_numpy(np.concatenate(tabs)).to(dev, non_blocking=True)        # one H2D copy per step
+        rects_d = torch.from_numpy(rects).to(dev, non_blocking=True)
+        fg = ops.crop_resize_flip(ds.images, reg, table[: 2 * n], h, w, id_stride, want_ids=True)
+        bg = ops.crop_resize_flip(ds.images, None, table[2 * n:], h, w, 1, want_ids=False)
+        ops.erase_rect(bg[0], rects_d)
+        imgs = torch.cat([fg[0], bg[0]])
+    else:
+        colour = jitter_table(rng, 4 * n)
+        blur, rmax = blur_table(rng, 4 * n)
+        rects4 = np.concatenate([np.zeros((2 * n, 4), dtype=np.int32), rects])           # foreground views: nothing erased
+        parts = [np.concatenate(tabs), colour, blur, rects4]
+        flat = torch.from_numpy(np.concatenate([p.ravel() for p in parts])).to(dev, non_blocking=True)   # one H2D copy per step
+        views, o = [], 0
+        for p in parts:
+            views.append(flat[o:o + p.size].view(p.shape))
+            o += p.size
+        table, colour_d, blur_d, rects_d = views
+        rgbx = torch.empty((4 * n, h, w), dtype=torch.int32, device=dev)
+        fg = ops.crop_resize_flip(ds.images, reg, table[: 2 * n], h, w, id_stride, want_ids=True, want_f32=False,
+                                  out_rgbx=rgbx[: 2 * n])
+        ops.pil_resize_crop(ds.images, table[2 * n:], h, w, out_rgbx=rgbx[2 * n:])
+        ops.color_ops(rgbx, colour_d)
+        imgs = ops.blur_to_tensor(rgbx, blur_d, rects_d, rmax)
+    out["img_a"], out["img_b"] = imgs[:n], imgs[n:2 * n]
     out["pixel_ids_a"], out["pixel_ids_b"] = fg[1][:n], fg[1][n:]
     out["region_ids_a"], out["region_ids_b"] = fg[2][:n], fg[2][n:]
-    out["bg0"], out["bg1"] = bg[0][:n], bg[0][n:]
+    out["bg0"], out["bg1"] = imgs[2 * n:3 * n], imgs[3 * n:]
     return out

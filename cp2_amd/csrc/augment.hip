@@ -16,8 +16,9 @@ struct CropArgs {
     const int64_t* src_region;                   // [N][Hs][Ws] region ids, or NULL (region id = pixel id, loader.py:84-85)
     int N, Hs, Ws;
     const int32_t* params;                       // [B][8]: source index, top, left, crop h, crop w, flip, 0, 0
-    float* out_img; int64_t* out_pix; int64_t* out_reg;   // [B][3][H][W], [B][H][W] (ids: either may be NULL)
+    float* out_img; int64_t* out_pix; int64_t* out_reg;   // [B][3][H][W], [B][H][W] (any may be NULL)
     int B, H, W, id_stride;
+    uint32_t* out_rgbx;                          // [B][H][W] R | G<<8 | B<<16, or NULL: the view in uint8 for the photometric stages
 };
 
 __device__ __forceinline__ float src_px(const CropArgs& a, int64_t plane, int y, int x) {
@@ -34,6 +35,7 @@ __global__ __launch_bounds__(256) void crop_resize_flip_kernel(CropArgs a) {
     // ---- id maps: nearest neighbour, source cell = floor(dst * crop / out) in exact integer arithmetic
     const int sy = top + (int)(((int64_t)y * ch) / a.H), sx = left + (int)(((int64_t)xr * cw) / a.W);
     int64_t pid;
+    int ry = sy, rx = sx;                        // the source cell whose id this output pixel carries
     if (a.id_stride <= 1) {
         pid = (int64_t)sy * a.Ws + sx + 1;
     } else {
@@ -42,11 +44,13 @@ __global__ __launch_bounds__(256) void crop_resize_flip_kernel(CropArgs a) {
         const int s = a.id_stride, o = s / 2;
         const int hs = (a.Hs - o + s - 1) / s, ws = (a.Ws - o + s - 1) / s;
         const int i = (int)(((int64_t)(2 * sy + 1) * hs) / (2 * a.Hs)), j = (int)(((int64_t)(2 * sx + 1) * ws) / (2 * a.Ws));
-        pid = (int64_t)(o + s * i) * a.Ws + (o + s * j) + 1;
+        ry = o + s * i, rx = o + s * j;
+        pid = (int64_t)ry * a.Ws + rx + 1;
     }
     const int64_t o_id = ((int64_t)b * a.H + y) * a.W + x;
     if (a.out_pix) a.out_pix[o_id] = pid;
-    if (a.out_reg) a.out_reg[o_id] = a.src_region ? a.src_region[((int64_t)n * a.Hs + sy) * a.Ws + sx] : pid;
+    // the region map goes through the same rescale_ids + INTER_NEAREST_EXACT round trip as the pixel ids (loader.py:75-83)
+    if (a.out_reg) a.out_reg[o_id] = a.src_region ? a.src_region[((int64_t)n * a.Hs + ry) * a.Ws + rx] : pid;
     // ---- image: bilinear with half-pixel centres, edges replicated; products and sums rounded one by one
     const float fy = ((float)y + 0.5f) * ((float)ch / (float)a.H) - 0.5f;
     const float fx = ((float)xr + 0.5f) * ((float)cw / (float)a.W) - 0.5f;
@@ -54,14 +58,21 @@ __global__ __launch_bounds__(256) void crop_resize_flip_kernel(CropArgs a) {
     const int y0 = (int)floorf(cy), x0 = (int)floorf(cx);
     const int y1 = min(y0 + 1, ch - 1), x1 = min(x0 + 1, cw - 1);
     const float wy = cy - (float)y0, wx = cx - (float)x0;
+    uint32_t packed = 0;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const int64_t plane = ((int64_t)n * 3 + c) * a.Hs * a.Ws;
         const float p00 = src_px(a, plane, top + y0, left + x0), p01 = src_px(a, plane, top + y0, left + x1);
         const float p10 = src_px(a, plane, top + y1, left + x0), p11 = src_px(a, plane, top + y1, left + x1);
         const float r0 = p00 * (1.0f - wx) + p01 * wx, r1 = p10 * (1.0f - wx) + p11 * wx;
-        a.out_img[(((int64_t)b * 3 + c) * a.H + y) * a.W + x] = r0 * (1.0f - wy) + r1 * wy;
+        const float v = r0 * (1.0f - wy) + r1 * wy;
+        if (a.out_img) a.out_img[(((int64_t)b * 3 + c) * a.H + y) * a.W + x] = v;
+        // uint8 view for the photometric stages: value * 255 rounded half up (cv2.resize would hand albumentations a
+        // uint8 image here; its 11-bit fixed-point interpolation is not restated -- parity-unpinned)
+        const int q = (int)floorf(v * 255.0f + 0.5f);
+        packed |= (uint32_t)(q < 0 ? 0 : (q > 255 ? 255 : q)) << (8 * c);
     }
+    if (a.out_rgbx) a.out_rgbx[o_id] = packed;
 }
 
 // RandomErasing(value=0): img[b, :, top:top+h, left:left+w] = 0 (exactly), rects [B][4] = top, left, h, w (h = 0: skip)
@@ -76,11 +87,11 @@ __global__ __launch_bounds__(256) void erase_rect_kernel(float* __restrict__ img
 
 CP2_API int cp2_crop_resize_flip(const void* src, int src_is_u8, const int64_t* src_region, int N, int Hs, int Ws,
                                  const int32_t* params, float* out_img, int64_t* out_pix, int64_t* out_reg, int B, int H,
-                                 int W, int id_stride, void* stream) {
-    if (!src || !params || !out_img) return CP2_ERR_NULL;
+                                 int W, int id_stride, uint32_t* out_rgbx, void* stream) {
+    if (!src || !params || (!out_img && !out_rgbx)) return CP2_ERR_NULL;
     if (N <= 0 || Hs <= 0 || Ws <= 0 || B <= 0 || H <= 0 || W <= 0 || id_stride < 1) return CP2_ERR_SHAPE;
     if (B > 65535 || H > 65535) return CP2_ERR_UNSUPPORTED;
-    CropArgs a{src, src_is_u8, src_region, N, Hs, Ws, params, out_img, out_pix, out_reg, B, H, W, id_stride};
+    CropArgs a{src, src_is_u8, src_region, N, Hs, Ws, params, out_img, out_pix, out_reg, B, H, W, id_stride, out_rgbx};
     hipLaunchKernelGGL(crop_resize_flip_kernel, dim3(cp2_cdiv(W, 256), H, B), dim3(256), 0, cp2_stream(stream), a);
     return cp2_launch_status();
 }

@@ -98,7 +98,11 @@ def get_args(argv=None):
     p.add_argument("--synthetic", action="store_true", help="on-device synthetic batches (loader contract of SURVEY 8d)")
     p.add_argument("--tensor_dataset", default="", type=str,
                    help="torch file {'images': uint8/float32 [N,3,H,W], optional 'region_ids': [N,H,W]}: resident in HBM, "
-                        "augmented on the device (cp2_amd/augment.py)")
+                        "augmented on the device (cp2_amd/augment.py): two-crop views with id maps, backgrounds with the "
+                        "erased rectangle, and -- for uint8 images -- ColorJitter / grayscale / GaussianBlur as reference "
+                        "main.py:204-245 applies them (a float32 dataset gets the geometric transforms only)")
+    p.add_argument("--no_photometric", action="store_true",
+                   help="with --tensor_dataset: geometric transforms only (no ColorJitter / grayscale / GaussianBlur)")
     p.add_argument("--steps_per_epoch", default=100, type=int, help="with --synthetic: steps per epoch")
     p.add_argument("--amp", default="bf16", choices=["none", "bf16"], help="encoder autocast dtype")
     p.add_argument("--no_channels_last", action="store_true")
@@ -212,7 +216,6 @@ def main_worker(rank, args):
         steps_per_epoch = (len(dataset) // world) // per_gpu
         if steps_per_epoch < 1:
             raise ValueError(f"--tensor_dataset holds {len(dataset)} images: fewer than one batch of {args.batch_size}")
-        rng = np.random.default_rng(args.seed + 7919 * rank)
         use_regions = args.mapping_type in (builder.MappingType.REGION_ID, builder.MappingType.PIXEL_REGION_ID)
     elif args.synthetic:
         steps_per_epoch = args.steps_per_epoch
@@ -227,6 +230,7 @@ def main_worker(rank, args):
         t0, seen = time.time(), 0
         if dataset is not None:
             order = [s.indices(epoch) for s in samplers]
+            rng = np.random.default_rng([args.seed, rank, epoch])      # a resumed run draws epoch e's parameters again
         for i in range(steps_per_epoch):
             if step > args.max_steps:
                 break
@@ -234,7 +238,8 @@ def main_worker(rank, args):
                 sl = slice(i * per_gpu, (i + 1) * per_gpu)
                 batch = augment.make_step_batch(dataset, order[0][sl], order[1][sl], order[2][sl], args.img_height,
                                                 args.img_width, rng, args.foreground_min, args.foreground_max,
-                                                id_stride=args.pixel_ids_stride, use_regions=use_regions)
+                                                id_stride=args.pixel_ids_stride, use_regions=use_regions,
+                                                photometric=False if args.no_photometric else None)
             else:
                 batch = synthetic.make_batch(per_gpu, args.img_height, args.img_width, device,
                                              seed=args.seed + rank + 1000 * step, foreground_min=args.foreground_min,

@@ -109,23 +109,82 @@ def gather_rows(src: torch.Tensor, idx: torch.Tensor, err_flag: Optional[torch.T
 
 # ---------------------------------------------------------------- f1: on-device augmentation
 def crop_resize_flip(src: torch.Tensor, src_region: Optional[torch.Tensor], params: torch.Tensor, H: int, W: int,
-                     id_stride: int = 1, want_ids: bool = True):
+                     id_stride: int = 1, want_ids: bool = True, want_f32: bool = True, out_rgbx: Optional[torch.Tensor] = None):
     """RandomResizedCrop + HorizontalFlip with explicit parameters (reference loader.py:50-118, main.py:206-216).
     src: [N,3,Hs,Ws] uint8 / float32 on the GPU; params: int32 [B,8] device table (augment.crop_table).
-    Returns (img [B,3,H,W] f32, pixel_ids [B,H,W] int64 or None, region_ids or None)."""
+    Returns (img [B,3,H,W] f32 or None, pixel_ids [B,H,W] int64 or None, region_ids or None); out_rgbx: optional int32
+    [B,H,W] tensor that receives the view as packed uint8 RGB for the photometric stages (color_ops, blur_to_tensor)."""
     lib = _lib.load()
     if not src.is_cuda or src.dtype not in (torch.uint8, torch.float32) or src.dim() != 4 or src.shape[1] != 3:
         raise _lib.Cp2LibraryError("crop_resize_flip: src must be a uint8 / float32 [N,3,Hs,Ws] GPU tensor")
     N, _, Hs, Ws = src.shape
     B = params.shape[0]
-    img = torch.empty((B, 3, H, W), dtype=torch.float32, device=src.device)
+    if not want_f32 and out_rgbx is None:
+        raise ValueError("crop_resize_flip: nothing to write (want_f32=False and no out_rgbx)")
+    if out_rgbx is not None and (tuple(out_rgbx.shape) != (B, H, W) or out_rgbx.dtype != torch.int32):
+        raise ValueError("crop_resize_flip: out_rgbx must be int32 [B,H,W]")
+    img = torch.empty((B, 3, H, W), dtype=torch.float32, device=src.device) if want_f32 else None
     pix = torch.empty((B, H, W), dtype=torch.int64, device=src.device) if want_ids else None
     reg = torch.empty((B, H, W), dtype=torch.int64, device=src.device) if want_ids else None
     rc = lib.cp2_crop_resize_flip(_dev(src, "src"), int(src.dtype == torch.uint8), _opt(src_region, "src_region", torch.int64),
-                                  N, Hs, Ws, _dev(params, "params", torch.int32), img.data_ptr(), _opt(pix, "pix"),
-                                  _opt(reg, "reg"), B, H, W, int(id_stride), _stream())
+                                  N, Hs, Ws, _dev(params, "params", torch.int32), _opt(img, "img"), _opt(pix, "pix"),
+                                  _opt(reg, "reg"), B, H, W, int(id_stride), _opt(out_rgbx, "out_rgbx"), _stream())
     _lib.check(rc, "cp2_crop_resize_flip")
     return img, pix, reg
+
+
+def pil_resize_crop(src: torch.Tensor, params: torch.Tensor, H: int, W: int, out_rgbx: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Background RandomResizedCrop + flip in Pillow's arithmetic: img.crop(box).resize((W, H), BILINEAR)
+    (reference main.py:209-211,217).  src: uint8 [N,3,Hs,Ws]; params as crop_resize_flip.  Returns int32 [B,H,W] packed
+    uint8 RGB (R | G<<8 | B<<16)."""
+    lib = _lib.load()
+    if not src.is_cuda or src.dtype != torch.uint8 or src.dim() != 4 or src.shape[1] != 3:
+        raise _lib.Cp2LibraryError("pil_resize_crop: src must be a uint8 [N,3,Hs,Ws] GPU tensor (PIL images are uint8)")
+    N, _, Hs, Ws = src.shape
+    B = params.shape[0]
+    if out_rgbx is None:
+        out_rgbx = torch.empty((B, H, W), dtype=torch.int32, device=src.device)
+    elif tuple(out_rgbx.shape) != (B, H, W) or out_rgbx.dtype != torch.int32:
+        raise ValueError("pil_resize_crop: out_rgbx must be int32 [B,H,W]")
+    nbytes = lib.cp2_pil_resize_workspace_bytes(B, Hs, Ws, H, W)
+    if nbytes <= 0:
+        raise ValueError("pil_resize_crop: bad shapes")
+    ws = torch.empty(nbytes // 4, dtype=torch.int32, device=src.device)
+    rc = lib.cp2_pil_resize_crop(_dev(src, "src"), N, Hs, Ws, _dev(params, "params", torch.int32), _dev(out_rgbx, "out_rgbx"),
+                                 B, H, W, ws.data_ptr(), nbytes, _stream())
+    _lib.check(rc, "cp2_pil_resize_crop")
+    return out_rgbx
+
+
+COLOR_PARAMS = 12          # CP2_COLOR_PARAMS
+BLUR_MAX_RADIUS = 4        # CP2_BLUR_MAX_RADIUS
+
+
+def color_ops(rgbx: torch.Tensor, params: torch.Tensor) -> None:
+    """In place ColorJitter + RandomGrayscale on packed uint8 RGB [B,H,W] (reference main.py:212-215; Pillow's
+    ImageEnhance / adjust_hue / convert("L") arithmetic).  params: int32 [B,12] (augment.jitter_table)."""
+    lib = _lib.load()
+    B, H, W = rgbx.shape
+    if rgbx.dtype != torch.int32 or tuple(params.shape) != (B, COLOR_PARAMS):
+        raise ValueError(f"color_ops: rgbx int32 [B,H,W] and params int32 [B,{COLOR_PARAMS}] expected")
+    lsum = torch.empty(B, dtype=torch.int64, device=rgbx.device)
+    rc = lib.cp2_color_ops(_dev(rgbx, "rgbx"), _dev(params, "params", torch.int32), lsum.data_ptr(), B, H, W, _stream())
+    _lib.check(rc, "cp2_color_ops")
+
+
+def blur_to_tensor(rgbx: torch.Tensor, params: torch.Tensor, rects: Optional[torch.Tensor], rmax: int) -> torch.Tensor:
+    """GaussianBlur (Pillow's three box passes per axis) + ToTensor + RandomErasing(value=0) in one pass (reference
+    main.py:216-224, loader.py:121-152).  params: int32 [B,4] (augment.blur_table), rects: int32 [B,4] or None.
+    Returns float32 [B,3,H,W]."""
+    lib = _lib.load()
+    B, H, W = rgbx.shape
+    if rgbx.dtype != torch.int32 or tuple(params.shape) != (B, 4) or (rects is not None and tuple(rects.shape) != (B, 4)):
+        raise ValueError("blur_to_tensor: rgbx int32 [B,H,W], params int32 [B,4], rects int32 [B,4] expected")
+    out = torch.empty((B, 3, H, W), dtype=torch.float32, device=rgbx.device)
+    rc = lib.cp2_blur_to_tensor(_dev(rgbx, "rgbx"), _dev(params, "params", torch.int32), _opt(rects, "rects", torch.int32),
+                                out.data_ptr(), B, H, W, int(rmax), _stream())
+    _lib.check(rc, "cp2_blur_to_tensor")
+    return out
 
 
 def erase_rect(img: torch.Tensor, rects: torch.Tensor) -> None:

@@ -215,13 +215,41 @@ int cp2_masked_quantiles_multi(int njobs, const float* const* x, const int64_t* 
  * HorizontalFlip parameters drawn by the caller).  out_img [B,3,H,W]: bilinear, half-pixel centres, replicated edges;
  * out_pix / out_reg [B,H,W] int64 (either may be NULL): nearest neighbour, source cell floor(dst*crop/out); pixel id of
  * source cell (y,x) = y*Ws + x + 1 at id_stride 1, else the id of the centre tap of its stride block mapped back by
- * INTER_NEAREST_EXACT (loader.py:66-73); region id = src_region, or the pixel id when src_region is NULL. */
+ * INTER_NEAREST_EXACT (loader.py:66-73); region id = src_region read at that same cell (loader.py:75-83), or the pixel id
+ * when src_region is NULL.  out_img may be NULL when out_rgbx is given: out_rgbx [B,H,W] receives the view as uint8
+ * (R | G<<8 | B<<16 per pixel, value*255 rounded half up) for the photometric stages below. */
 int cp2_crop_resize_flip(const void* src, int src_is_u8, const int64_t* src_region, int N, int Hs, int Ws,
                          const int32_t* params, float* out_img, int64_t* out_pix, int64_t* out_reg, int B, int H,
-                         int W, int id_stride, void* stream);
+                         int W, int id_stride, uint32_t* out_rgbx, void* stream);
 /* RandomErasing(p=1, value=0) of the background view (main.py:218-224): img[b,:,top:top+h,left:left+w] = 0 exactly;
  * rects: device int32 [B,4] = {top, left, h, w} (h = 0 skips the sample).  In place. */
 int cp2_erase_rect(float* img, const int32_t* rects, int B, int H, int W, void* stream);
+
+/* ---- f1, photometric half: the image-value transforms of the reference's loaders in Pillow's arithmetic --------------
+ * main.py:204-225 (background views, torchvision on PIL images), loader.py:121-152 (GaussianBlur of both kinds of view).
+ * Working format: uint32 per pixel = R | G<<8 | B<<16, [B,H,W].  Host-drawn parameters in device tables.
+ *
+ * cp2_pil_resize_crop: RandomResizedCrop + HorizontalFlip of a background view = img.crop(box).resize((W,H), BILINEAR)
+ * (Pillow Resample.c: separable, antialiased when shrinking, 22-bit integer taps, uint8 after the horizontal pass).
+ * src: uint8 [N,3,Hs,Ws]; params: int32 [B,8] as cp2_crop_resize_flip; workspace: int32 scratch of
+ * cp2_pil_resize_workspace_bytes(B,Hs,Ws,H,W) bytes (coefficient tables, written by a first launch). */
+int cp2_pil_resize_ksize(int Hs, int Ws, int H, int W);
+int64_t cp2_pil_resize_workspace_bytes(int B, int Hs, int Ws, int H, int W);
+int cp2_pil_resize_crop(const unsigned char* src, int N, int Hs, int Ws, const int32_t* params, uint32_t* out_rgbx,
+                        int B, int H, int W, int32_t* workspace, int64_t workspace_bytes, void* stream);
+/* cp2_color_ops: ColorJitter + RandomGrayscale in place (Pillow ImageEnhance / Blend.c / Convert.c arithmetic).
+ * params: int32 [B,CP2_COLOR_PARAMS]: [0..3] adjustments in application order (0 brightness, 1 contrast, 2 saturation,
+ * 3 hue, -1 none), [4..6] float bits of the brightness / contrast / saturation factors, [7] uint8(hue_factor*255),
+ * [8] grayscale flag.  lsum: uint64 [B] scratch (zeroed by the call; receives the L sum the contrast step needs). */
+#define CP2_COLOR_PARAMS 12
+int cp2_color_ops(uint32_t* img_rgbx, const int32_t* params, uint64_t* lsum, int B, int H, int W, void* stream);
+/* cp2_blur_to_tensor: ImageFilter.GaussianBlur(sigma) (Pillow BoxBlur.c: three box passes per axis, 24-bit weights,
+ * replicated edges) + ToTensor (uint8/255 -> CHW float) + RandomErasing(value=0) in one pass.
+ * params: int32 [B,4] = {blur on, integer box radius, ww, fw}; rects: int32 [B,4] = {top,left,h,w} or NULL;
+ * out: float [B,3,H,W]; rmax: the largest integer radius in params (<= CP2_BLUR_MAX_RADIUS; sizes the LDS halo). */
+#define CP2_BLUR_MAX_RADIUS 4
+int cp2_blur_to_tensor(const uint32_t* img_rgbx, const int32_t* params, const int32_t* rects, float* out, int B, int H,
+                       int W, int rmax, void* stream);
 
 /* ---- optimizer step of the query encoder on the flat parameter buffer ---------------- main.py:467-477, :640-642
  * torch.optim.SGD(momentum, weight_decay) (dampening 0, no Nesterov), bit-identical to torch's default multi-tensor

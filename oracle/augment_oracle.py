@@ -1,0 +1,275 @@
+"""CPU restatement of the photometric / resampling half of the reference's input pipeline -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/ and tests/golden/make_augment_goldens.py import this module; the product path (cp2_amd/augment.py,
+csrc/photometric.hip) never does.
+
+What the reference runs (main.py:204-245, loader.py:121-152) is torchvision / albumentations code on top of two
+third-party image libraries that are not part of /root/reference:
+
+  * background views: torchvision transforms on PIL images -- RandomResizedCrop = `img.crop(box).resize(size, BILINEAR)`,
+    ColorJitter = `ImageEnhance.{Brightness,Contrast,Color}(img).enhance(f)` and the HSV round trip of `adjust_hue`,
+    RandomGrayscale = `img.convert("L")` replicated to three bands, GaussianBlur = `img.filter(ImageFilter.GaussianBlur(s))`
+    (loader.py:121-131), ToTensor = uint8 / 255.  The arithmetic lives in **Pillow** (un-pinned in requirements.txt;
+    12.2.0 is installed in the build image): Resample.c (fixed-point separable convolution, 22-bit coefficients, uint8
+    after each pass), Blend.c (float interpolation, truncation), Convert.c (rgb2l, rgb2hsv / hsv2rgb after colorsys),
+    BoxBlur.c (Gaussian = three box passes per axis, 24-bit weights).  This file restates those published algorithms in
+    numpy, and tests/test_augment_photometric.py / make_augment_goldens.py pin the restatement against Pillow itself.
+  * foreground views: albumentations on cv2 (RandomResizedCrop = cv2.resize INTER_LINEAR, ColorJitter / ToGray by cv2
+    LUTs) -- cv2 and albumentations are absent here, so that arithmetic stays **parity-unpinned**; only the foreground's
+    Gaussian blur is Pillow's (loader.py:136-152, the same ImageFilter.GaussianBlur).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+PRECISION_BITS = 32 - 8 - 2          # Pillow Resample.c: coefficients as 22-bit fixed point
+
+
+# --------------------------------------------------------------------------- Resample.c: bilinear, uint8
+def resample_coeffs(in_size: int, in0: float, in1: float, out_size: int):
+    """precompute_coeffs + normalize_coeffs_8bpc for the BILINEAR filter (support 1): per output index the first input
+    index, the tap count, and the integer taps.  Down-scaling widens the triangle by the scale (antialiasing)."""
+    scale = (in1 - in0) / out_size
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    ss = 1.0 / filterscale
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    kk = np.zeros((out_size, ksize), dtype=np.int32)
+    for xx in range(out_size):
+        center = in0 + (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        xmin = max(xmin, 0)
+        xmax = int(center + support + 0.5)
+        xmax = min(xmax, in_size) - xmin
+        k = np.zeros(ksize, dtype=np.float64)
+        ww = 0.0
+        for x in range(xmax):
+            v = (x + xmin - center + 0.5) * ss
+            v = -v if v < 0 else v
+            w = 1.0 - v if v < 1.0 else 0.0
+            k[x] = w
+            ww += w
+        if ww != 0.0:
+            k[:xmax] = k[:xmax] / ww
+        bounds[xx] = (xmin, xmax)
+        for x in range(ksize):                       # (int)(k * (1 << 22) +- 0.5): round half away from zero
+            v = k[x] * (1 << PRECISION_BITS)
+            kk[xx, x] = int(v - 0.5) if k[x] < 0 else int(v + 0.5)
+    return bounds, kk
+
+
+def _resample_axis0(img: np.ndarray, out_size: int) -> np.ndarray:
+    """One pass along axis 0 of a uint8 array [n, ...] (the whole extent is the box)."""
+    bounds, kk = resample_coeffs(img.shape[0], 0.0, float(img.shape[0]), out_size)
+    out = np.empty((out_size,) + img.shape[1:], dtype=np.uint8)
+    src = img.astype(np.int64)
+    for i in range(out_size):
+        xmin, n = bounds[i]
+        acc = np.full(img.shape[1:], 1 << (PRECISION_BITS - 1), dtype=np.int64)
+        for t in range(n):
+            acc += src[xmin + t] * int(kk[i, t])
+        out[i] = np.clip(acc >> PRECISION_BITS, 0, 255).astype(np.uint8)
+    return out
+
+
+def pil_crop_resize(img: np.ndarray, box, h: int, w: int) -> np.ndarray:
+    """torchvision F.resized_crop on a PIL image = img.crop((left, top, left+cw, top+ch)).resize((w, h), BILINEAR).
+    img: uint8 [Hs, Ws, 3]; box = (top, left, ch, cw).  Pillow runs the horizontal pass first and rounds to uint8 between
+    the passes; a pass whose size does not change is skipped."""
+    top, left, ch, cw = [int(v) for v in box]
+    cur = img[top:top + ch, left:left + cw]
+    if cw != w:
+        cur = np.swapaxes(_resample_axis0(np.swapaxes(cur, 0, 1), w), 0, 1)
+    if ch != h:
+        cur = _resample_axis0(cur, h)
+    return np.ascontiguousarray(cur)
+
+
+# --------------------------------------------------------------------------- Convert.c
+def rgb_to_l(img: np.ndarray) -> np.ndarray:
+    """L24 / rgb2l: (R*19595 + G*38470 + B*7471 + 0x8000) >> 16."""
+    r, g, b = (img[..., c].astype(np.int64) for c in range(3))
+    return ((r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16).astype(np.uint8)
+
+
+def rgb_to_hsv(img: np.ndarray) -> np.ndarray:
+    """rgb2hsv_row (after colorsys.rgb_to_hsv): float arithmetic, hue and saturation truncated to uint8."""
+    f32 = np.float32
+    r, g, b = (img[..., c].astype(np.int32) for c in range(3))
+    maxc, minc = np.maximum(r, np.maximum(g, b)), np.minimum(r, np.minimum(g, b))
+    grey = maxc == minc
+    cr = np.where(grey, 1, maxc - minc).astype(f32)
+    mx = np.where(maxc == 0, 1, maxc).astype(f32)
+    s = cr / mx
+    rc, gc, bc = (maxc - r).astype(f32) / cr, (maxc - g).astype(f32) / cr, (maxc - b).astype(f32) / cr
+    # the constants 2.0 / 4.0 / 6.0 / 1.0 are doubles in the C source: these sums run in double and land in a float
+    d = np.float64
+    h = np.where(r == maxc, (bc - gc).astype(d), np.where(g == maxc, 2.0 + rc.astype(d) - bc.astype(d), 4.0 + gc.astype(d) - rc.astype(d)))
+    h = h.astype(f32)
+    h = np.fmod(h.astype(d) / 6.0 + 1.0, 1.0).astype(f32)
+    uh = np.clip((h.astype(d) * 255.0).astype(np.int64), 0, 255)
+    us = np.clip((s.astype(d) * 255.0).astype(np.int64), 0, 255)
+    out = np.stack([np.where(grey, 0, uh), np.where(grey, 0, us), maxc], -1)
+    return out.astype(np.uint8)
+
+
+def _round_half_away(x: np.ndarray) -> np.ndarray:
+    return np.where(x >= 0, np.floor(x + 0.5), np.ceil(x - 0.5)).astype(np.int64)
+
+
+def hsv_to_rgb(img: np.ndarray) -> np.ndarray:
+    """hsv2rgb (after colorsys.hsv_to_rgb): sector from floor(h*6/255), p / q / t by C round()."""
+    d, f32 = np.float64, np.float32
+    h, s, v = (img[..., c].astype(np.int32) for c in range(3))
+    hf = h.astype(f32).astype(d) * 6.0 / 255.0
+    i = np.floor(hf).astype(np.int64)
+    f = (hf - i.astype(f32).astype(d)).astype(f32)
+    fs = (s.astype(f32).astype(d) / 255.0).astype(f32)
+    vf = v.astype(f32).astype(d)
+    p = np.clip(_round_half_away(vf * (1.0 - fs.astype(d))), 0, 255)
+    q = np.clip(_round_half_away(vf * (1.0 - fs.astype(d) * f.astype(d))), 0, 255)
+    t = np.clip(_round_half_away(vf * (1.0 - fs.astype(d) * (1.0 - f.astype(d)))), 0, 255)
+    sect = i % 6
+    table = [(v, t, p), (q, v, p), (p, v, t), (p, q, v), (t, p, v), (v, p, q)]
+    out = np.zeros(img.shape, dtype=np.int64)
+    for k, (rr, gg, bb) in enumerate(table):
+        m = sect == k
+        out[..., 0] = np.where(m, rr, out[..., 0])
+        out[..., 1] = np.where(m, gg, out[..., 1])
+        out[..., 2] = np.where(m, bb, out[..., 2])
+    grey = s == 0
+    for c in range(3):
+        out[..., c] = np.where(grey, v, out[..., c])
+    return out.astype(np.uint8)
+
+
+# --------------------------------------------------------------------------- Blend.c + ImageEnhance
+def blend(deg: np.ndarray, img: np.ndarray, factor: float) -> np.ndarray:
+    """Image.blend(degenerate, image, factor): in1 + alpha * (in2 - in1) in float, truncated; clipped when alpha is
+    outside [0, 1]."""
+    f32 = np.float32
+    a = f32(factor)
+    v = (deg.astype(np.int32).astype(f32) + (a * (img.astype(np.int32) - deg.astype(np.int32)).astype(f32)).astype(f32)).astype(f32)
+    if 0.0 <= float(a) <= 1.0:
+        return v.astype(np.int64).astype(np.uint8)
+    return np.where(v <= 0.0, 0, np.where(v >= 255.0, 255, v.astype(np.int64))).astype(np.uint8)
+
+
+def adjust_brightness(img: np.ndarray, factor: float) -> np.ndarray:
+    return blend(np.zeros_like(img), img, factor)
+
+
+def contrast_mean(img: np.ndarray) -> int:
+    """int(ImageStat.Stat(img.convert("L")).mean[0] + 0.5)"""
+    l = rgb_to_l(img)
+    return int(float(l.astype(np.int64).sum()) / float(l.size) + 0.5)
+
+
+def adjust_contrast(img: np.ndarray, factor: float) -> np.ndarray:
+    return blend(np.full_like(img, contrast_mean(img)), img, factor)
+
+
+def adjust_saturation(img: np.ndarray, factor: float) -> np.ndarray:
+    return blend(np.repeat(rgb_to_l(img)[..., None], 3, -1), img, factor)
+
+
+def adjust_hue_shift(img: np.ndarray, shift: int) -> np.ndarray:
+    """HSV round trip with the hue band advanced by `shift` (uint8 arithmetic, wrap-around)."""
+    hsv = rgb_to_hsv(img)
+    hsv[..., 0] = ((hsv[..., 0].astype(np.int64) + int(shift)) % 256).astype(np.uint8)
+    return hsv_to_rgb(hsv)
+
+
+def adjust_hue(img: np.ndarray, factor: float) -> np.ndarray:
+    """torchvision F_pil.adjust_hue: HSV, h += np.uint8(factor * 255) (truncation toward zero, wrap-around), back to RGB."""
+    return adjust_hue_shift(img, int(factor * 255) % 256)
+
+
+def to_grayscale3(img: np.ndarray) -> np.ndarray:
+    """RandomGrayscale: img.convert("L") replicated to three bands."""
+    return np.repeat(rgb_to_l(img)[..., None], 3, -1)
+
+
+JITTER_OPS = (adjust_brightness, adjust_contrast, adjust_saturation, adjust_hue)     # torchvision's fn_id order
+
+
+def color_jitter(img: np.ndarray, order, factors) -> np.ndarray:
+    """ColorJitter.forward: the four adjustments in the drawn order; factors[k] belongs to JITTER_OPS[k]."""
+    for k in order:
+        img = JITTER_OPS[int(k)](img, float(factors[int(k)]))
+    return img
+
+
+# --------------------------------------------------------------------------- BoxBlur.c
+def gaussian_box_radius(sigma: float, passes: int = 3) -> float:
+    """_gaussian_blur_radius: the (fractional) box radius whose `passes`-fold repetition has variance sigma^2."""
+    f32 = np.float32
+    sigma2 = f32(f32(f32(sigma) * f32(sigma)) / f32(passes))
+    big_l = f32(math.sqrt(12.0 * float(sigma2) + 1.0))
+    l = f32(math.floor((float(big_l) - 1.0) / 2.0))
+    a = f32(f32(f32(2) * l + f32(1)) * f32(f32(l * f32(l + f32(1))) - f32(f32(3) * sigma2)))
+    a = f32(a / f32(f32(6) * f32(sigma2 - f32(f32(l + f32(1)) * f32(l + f32(1))))))
+    return float(f32(l + a))
+
+
+def box_weights(radius: float):
+    """(integer radius, ww, fw) of ImagingHorizontalBoxBlur: 24-bit weights of the inner window and the two far pixels."""
+    f32 = np.float32
+    r = int(radius)
+    ww = int(f32(1 << 24) / f32(f32(f32(radius) * f32(2)) + f32(1)))
+    fw = ((1 << 24) - (r * 2 + 1) * ww) // 2
+    return r, ww, fw
+
+
+def _box_pass_axis1(img: np.ndarray, r: int, ww: int, fw: int) -> np.ndarray:
+    n = img.shape[1]
+    src = img.astype(np.int64)
+    idx = np.arange(n)
+    acc = np.zeros(img.shape, dtype=np.int64)
+    for d in range(-r, r + 1):
+        acc += src[:, np.clip(idx + d, 0, n - 1)]
+    far = src[:, np.clip(idx - r - 1, 0, n - 1)] + src[:, np.clip(idx + r + 1, 0, n - 1)]
+    return (((acc * ww + far * fw) & 0xFFFFFFFF) + (1 << 23) >> 24).astype(np.uint8)
+
+
+def gaussian_blur(img: np.ndarray, sigma: float) -> np.ndarray:
+    """img.filter(ImageFilter.GaussianBlur(sigma)) = ImagingGaussianBlur(passes=3): three box passes along x, then three
+    along y, uint8 after every pass, edges replicated."""
+    return box_blur3(img, *box_weights(gaussian_box_radius(sigma)))
+
+
+def box_blur3(img: np.ndarray, r: int, ww: int, fw: int) -> np.ndarray:
+    """ImagingBoxBlur(n = 3) with explicit weights."""
+    cur = img
+    for _ in range(3):
+        cur = _box_pass_axis1(cur, r, ww, fw)
+    cur = np.swapaxes(cur, 0, 1)
+    for _ in range(3):
+        cur = _box_pass_axis1(cur, r, ww, fw)
+    return np.ascontiguousarray(np.swapaxes(cur, 0, 1))
+
+
+def to_tensor(img: np.ndarray) -> np.ndarray:
+    """ToTensor: HWC uint8 -> CHW float32 / 255."""
+    return (img.astype(np.float32) / np.float32(255.0)).transpose(2, 0, 1)
+
+
+def background_view(img, box, h, w, jitter, gray, sigma, flip, rect):
+    """One background view of main.py:204-225 with explicit parameters: jitter = None or (order, factors); gray / flip
+    bool; sigma = None or the blur's sigma; rect = erase box (top, left, h, w)."""
+    cur = pil_crop_resize(img, box, h, w)
+    if jitter is not None:
+        cur = color_jitter(cur, *jitter)
+    if gray:
+        cur = to_grayscale3(cur)
+    if sigma is not None:
+        cur = gaussian_blur(cur, sigma)
+    if flip:
+        cur = cur[:, ::-1]
+    out = to_tensor(cur).copy()
+    t, l, eh, ew = [int(v) for v in rect]
+    out[:, t:t + eh, l:l + ew] = 0.0
+    return out

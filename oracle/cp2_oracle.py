@@ -436,7 +436,9 @@ def crop_resize_flip(src: np.ndarray, region: Optional[np.ndarray], box, flip: b
     sx = left + (xr * cw) // w
     pid_map = pixel_id_map(hs, ws, id_stride)
     pix = pid_map[sy][:, sx]
-    reg = region[sy][:, sx] if region is not None else pix
+    # loader.py:75-83: the region map goes through the same rescale_ids + INTER_NEAREST_EXACT round trip as the pixel
+    # ids, i.e. it is read at the very cell whose pixel id was kept (pixel id - 1 = row * ws + column of that cell)
+    reg = region.reshape(-1)[pix - 1] if region is not None else pix
     fy = (ys.astype(f32) + f32(0.5)) * (f32(ch) / f32(h)) - f32(0.5)
     fx = (xr.astype(f32) + f32(0.5)) * (f32(cw) / f32(w)) - f32(0.5)
     cy = np.minimum(np.maximum(fy, f32(0)), f32(ch - 1)).astype(f32)
@@ -451,6 +453,14 @@ def crop_resize_flip(src: np.ndarray, region: Optional[np.ndarray], box, flip: b
     r1 = (g(y1, x0) * (one - wx)).astype(f32) + (g(y1, x1) * wx).astype(f32)
     img = (r0.astype(f32) * (one - wy)).astype(f32) + (r1.astype(f32) * wy).astype(f32)
     return img.astype(f32), pix, reg
+
+
+def quantize_u8(img: np.ndarray) -> np.ndarray:
+    """The fp32 view as the uint8 image handed to the photometric stages: value * 255 rounded half up, (H, W, 3).
+    (cv2.resize would produce the foreground's uint8 image in the reference; its fixed-point arithmetic is not restated:
+    parity-unpinned)"""
+    q = np.floor(img.astype(np.float32) * np.float32(255.0) + np.float32(0.5))
+    return np.clip(q, 0, 255).astype(np.uint8).transpose(1, 2, 0)
 
 
 def erase_rect(img: np.ndarray, rect) -> np.ndarray:

@@ -110,19 +110,28 @@ def test_crop_resize_flip_and_erase_match_oracle_bit_for_bit(u8, stride):
 
 
 @pytest.mark.gpu
-def test_step_batch_contract_and_model_step():
+@pytest.mark.parametrize("photometric", [True, False])
+def test_step_batch_contract_and_model_step(photometric):
     """make_step_batch gives MODEL.forward its keyword set (main.py:616-628): dtypes, shapes, an exactly-zero rectangle
-    in every background, id maps of two crops of the same image that share ids -- and a model step runs on it."""
+    in every background, id maps of two crops of the same image that share ids -- and a model step runs on it.  With the
+    photometric transforms on (the default for a uint8 dataset) every view is a multiple of 1/255 (ToTensor of a uint8
+    image); the source pixels are >= 128 so that no colour adjustment can reach zero outside the erased rectangle."""
     import os
     from cp2_amd import builder, ops
     from cp2_amd.config import Config
     from cp2_amd.pretrain_types import PretrainType
     g = torch.Generator().manual_seed(0)
-    ds = A.DeviceDataset(torch.randint(1, 256, (40, 3, 96, 120), dtype=torch.uint8, generator=g))
+    ds = A.DeviceDataset(torch.randint(128, 256, (40, 3, 96, 120), dtype=torch.uint8, generator=g))
     rng = np.random.default_rng(0)
     b, H = 8, 64
     s = [A.EpochSampler(len(ds), 1, 0, seed).indices(0) for seed in (0, 1024, 2048)]
-    batch = A.make_step_batch(ds, s[0][:b], s[1][:b], s[2][:b], H, H, rng)
+    batch = A.make_step_batch(ds, s[0][:b], s[1][:b], s[2][:b], H, H, rng, photometric=photometric)
+    if photometric:
+        for k in ("img_a", "img_b", "bg0", "bg1"):
+            q = batch[k] * 255.0
+            assert (q - q.round()).abs().max() < 1e-4
+    else:
+        assert A.make_step_batch(ds, s[0][:b], s[1][:b], s[2][:b], H, H, np.random.default_rng(0), photometric=None)["img_a"].shape == (b, 3, H, H)
     assert set(batch) == {"img_a", "img_b", "bg0", "bg1", "pixel_ids_a", "pixel_ids_b", "region_ids_a", "region_ids_b"}
     for k in ("img_a", "img_b", "bg0", "bg1"):
         assert batch[k].shape == (b, 3, H, H) and batch[k].dtype == torch.float32 and 0 <= float(batch[k].min()) and float(batch[k].max()) <= 1

@@ -1,0 +1,264 @@
+"""f1, photometric half (reference main.py:204-225, loader.py:121-152): ColorJitter, grayscale, GaussianBlur and the
+background's crop + resize in Pillow's arithmetic.
+
+CPU: oracle/augment_oracle.py against tests/golden/augment_pillow.npz (outputs of Pillow itself, written by
+make_augment_goldens.py) bit for bit, and -- where Pillow is importable, as it is in the build image and on the GPU box --
+against live Pillow calls over random sizes / parameters and over all 2^24 colours for the HSV round trip.
+GPU: the HIP kernels (csrc/photometric.hip) through the C ABI against the same goldens and against the oracle on larger
+random cases, bit for bit; the foreground's uint8 view against the oracle's rule (that resampling is parity-unpinned:
+cv2 is not installed)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cp2_amd import augment as A
+from oracle import augment_oracle as P
+from oracle import cp2_oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "augment_pillow.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return dict(np.load(GOLD))
+
+
+def _order_and_factors(g, i):
+    order = [int(k) for k in g["view_order"][i] if k >= 0]
+    vf = g["view_factors"][i]
+    return order, (vf[0], vf[1], vf[2], vf[3])
+
+
+# ------------------------------------------------------------------ CPU: oracle == Pillow's outputs
+def test_oracle_single_operations_equal_pillow_goldens(gold):
+    g = gold
+    src, h, w = g["src"], g["resized"].shape[1], g["resized"].shape[2]
+    for i in range(len(src)):
+        assert np.array_equal(P.pil_crop_resize(src[i], g["boxes"][i], h, w), g["resized"][i]), i
+        assert np.array_equal(P.adjust_brightness(src[i], g["factors"][i, 0]), g["brightness"][i]), i
+        assert np.array_equal(P.adjust_contrast(src[i], g["factors"][i, 1]), g["contrast"][i]), i
+        assert np.array_equal(P.adjust_saturation(src[i], g["factors"][i, 2]), g["saturation"][i]), i
+        assert np.array_equal(P.adjust_hue(src[i], g["hue"][i]), g["hue_out"][i]), i
+        assert np.array_equal(P.rgb_to_l(src[i]), g["gray"][i]), i
+        assert np.array_equal(P.gaussian_blur(src[i], g["sigma"][i]), g["blurred"][i]), i
+
+
+def test_oracle_background_views_equal_pillow_goldens(gold):
+    g = gold
+    h, w = g["views"].shape[2:]
+    for i in range(len(g["views"])):
+        order, factors = _order_and_factors(g, i)
+        got = P.background_view(g["src"][g["view_idx"][i]], g["view_box"][i], h, w, (order, factors) if order else None,
+                                bool(g["view_gray"][i]), float(g["view_sigma"][i]) if g["view_sigma"][i] > 0 else None,
+                                bool(g["view_flip"][i]), g["view_rect"][i])
+        assert np.array_equal(got, g["views"][i]), i
+
+
+def test_oracle_against_live_pillow():
+    """Random sizes, boxes, factors; and the HSV conversions over every colour."""
+    Image = pytest.importorskip("PIL.Image")
+    from PIL import ImageEnhance, ImageFilter
+    rng = np.random.default_rng(7)
+    v = np.arange(0, 256, dtype=np.uint8)
+    allc = np.stack(np.meshgrid(v, v, v, indexing="ij"), -1).reshape(4096, 4096, 3)
+    assert np.array_equal(np.asarray(Image.fromarray(allc).convert("HSV")), P.rgb_to_hsv(allc))
+    assert np.array_equal(np.asarray(Image.fromarray(allc, "HSV").convert("RGB")), P.hsv_to_rgb(allc))
+    assert np.array_equal(np.asarray(Image.fromarray(allc).convert("L")), P.rgb_to_l(allc))
+    for it in range(40):
+        hs, ws = int(rng.integers(8, 200)), int(rng.integers(8, 200))
+        src = rng.integers(0, 256, (hs, ws, 3), dtype=np.uint8)
+        im = Image.fromarray(src)
+        f = float(rng.uniform(0.6, 1.4))
+        assert np.array_equal(np.asarray(ImageEnhance.Brightness(im).enhance(f)), P.adjust_brightness(src, f))
+        assert np.array_equal(np.asarray(ImageEnhance.Contrast(im).enhance(f)), P.adjust_contrast(src, f))
+        assert np.array_equal(np.asarray(ImageEnhance.Color(im).enhance(f)), P.adjust_saturation(src, f))
+        sg = float(rng.uniform(0.1, 2.0 if it % 4 else 5.0))
+        assert np.array_equal(np.asarray(im.filter(ImageFilter.GaussianBlur(radius=sg))), P.gaussian_blur(src, sg)), sg
+        ch, cw = int(rng.integers(1, hs + 1)), int(rng.integers(1, ws + 1))
+        top, left = int(rng.integers(0, hs - ch + 1)), int(rng.integers(0, ws - cw + 1))
+        H, W = int(rng.integers(1, 120)), int(rng.integers(1, 120))
+        want = np.asarray(im.crop((left, top, left + cw, top + ch)).resize((W, H), Image.BILINEAR))
+        assert np.array_equal(want, P.pil_crop_resize(src, (top, left, ch, cw), H, W)), (ch, cw, H, W)
+
+
+def test_host_tables_follow_the_transforms():
+    rng = np.random.default_rng(3)
+    t = A.jitter_table(rng, 4000)
+    applied = t[:, 0] >= 0
+    assert 0.77 < applied.mean() < 0.83 and 0.17 < t[:, 8].mean() < 0.23                     # p = 0.8, grayscale p = 0.2
+    assert all(sorted(r) == [0, 1, 2, 3] for r in t[applied][:200, :4].tolist()) and (t[~applied, :4] == -1).all()
+    f = t[:, 4:7].copy().view(np.float32)
+    assert f.min() >= 0.6 and f.max() <= 1.4 and abs(f.mean() - 1.0) < 0.02
+    assert set(np.unique(t[:, 7])) <= set(range(0, 26)) | set(range(231, 256))               # uint8(U(-0.1, 0.1) * 255) wraps
+    assert A.hue_shift_u8([-0.1, -0.05, -0.0001, 0.03, 0.1]).tolist() == [231, 244, 0, 7, 25]
+    b, rmax = A.blur_table(rng, 4000)
+    assert 0.46 < b[:, 0].mean() < 0.54 and rmax == 1 and (b[b[:, 0] == 0] == 0).all()      # sigma <= 2: box radius 0 or 1
+    for s in rng.uniform(0.05, 3.4, 300):                                                    # product-side copy == oracle's
+        assert A.gaussian_box(float(s)) == P.box_weights(P.gaussian_box_radius(float(s)))
+    r, ww, fw = A.gaussian_box(2.0)
+    assert (2 * r + 1) * ww + 2 * fw in ((1 << 24) - 1, 1 << 24)                             # the weights sum to one (24-bit)
+
+
+# ------------------------------------------------------------------ GPU: kernels == Pillow's outputs
+def _pack(img_hwc):
+    x = img_hwc.astype(np.int32)
+    return x[..., 0] | (x[..., 1] << 8) | (x[..., 2] << 16)
+
+
+def _unpack(t):
+    x = t.cpu().numpy().astype(np.int64)
+    return np.stack([x & 255, (x >> 8) & 255, (x >> 16) & 255], -1).astype(np.uint8)
+
+
+def _colour_row(order=(), factors=(1.0, 1.0, 1.0), hue=0.0, gray=False):
+    row = np.zeros(12, dtype=np.int32)
+    row[:4] = -1
+    row[:len(order)] = order
+    row[4:7] = np.asarray(factors, dtype=np.float32).view(np.int32)
+    row[7] = A.hue_shift_u8(hue)
+    row[8] = int(gray)
+    return row
+
+
+def _blur_row(sigma):
+    if sigma is None or sigma <= 0:
+        return np.zeros(4, dtype=np.int32)
+    r, ww, fw = A.gaussian_box(float(sigma))
+    return np.array([1, r, ww, fw], dtype=np.int32)
+
+
+@pytest.mark.gpu
+def test_kernels_single_operations_equal_pillow_goldens(gold):
+    from cp2_amd import ops
+    g = gold
+    src = g["src"]
+    n, hs, ws = src.shape[:3]
+    h, w = g["resized"].shape[1:3]
+    planar = torch.from_numpy(np.ascontiguousarray(src.transpose(0, 3, 1, 2))).cuda()
+    tab = torch.from_numpy(A.crop_table(np.arange(n), g["boxes"], np.zeros(n, dtype=bool))).cuda()
+    assert np.array_equal(_unpack(ops.pil_resize_crop(planar, tab, h, w)), g["resized"])
+    packed = torch.from_numpy(_pack(src)).cuda()
+    for name, k in (("brightness", 0), ("contrast", 1), ("saturation", 2)):
+        x = packed.clone()
+        rows = np.stack([_colour_row((k,), g["factors"][i]) for i in range(n)])
+        ops.color_ops(x, torch.from_numpy(rows).cuda())
+        assert np.array_equal(_unpack(x), g[name]), name
+    x = packed.clone()
+    ops.color_ops(x, torch.from_numpy(np.stack([_colour_row((3,), hue=g["hue"][i]) for i in range(n)])).cuda())
+    assert np.array_equal(_unpack(x), g["hue_out"])
+    x = packed.clone()
+    ops.color_ops(x, torch.from_numpy(np.stack([_colour_row(gray=True)] * n)).cuda())
+    assert np.array_equal(_unpack(x)[..., 0], g["gray"]) and np.array_equal(_unpack(x)[..., 1], g["gray"])
+    rows = np.stack([_blur_row(s) for s in g["sigma"]])
+    out = ops.blur_to_tensor(packed, torch.from_numpy(rows).cuda(), None, int(rows[:, 1].max()))
+    want = g["blurred"].astype(np.float32).transpose(0, 3, 1, 2) / np.float32(255.0)
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
+@pytest.mark.gpu
+def test_kernels_background_views_equal_pillow_goldens(gold):
+    """The whole background chain -- crop + resize + flip, colour adjustments in the drawn order, grayscale, blur,
+    ToTensor, erase -- in four launches for the batch, against Pillow's own output of the same chain."""
+    from cp2_amd import ops
+    g = gold
+    m = len(g["views"])
+    h, w = g["views"].shape[2:]
+    planar = torch.from_numpy(np.ascontiguousarray(g["src"].transpose(0, 3, 1, 2))).cuda()
+    tab = torch.from_numpy(A.crop_table(g["view_idx"], g["view_box"], g["view_flip"])).cuda()
+    rgbx = ops.pil_resize_crop(planar, tab, h, w)
+    rows = []
+    for i in range(m):
+        order, f = _order_and_factors(g, i)
+        rows.append(_colour_row(order, f[:3], f[3], bool(g["view_gray"][i])))
+    ops.color_ops(rgbx, torch.from_numpy(np.stack(rows)).cuda())
+    brow = np.stack([_blur_row(s) for s in g["view_sigma"]])
+    out = ops.blur_to_tensor(rgbx, torch.from_numpy(brow).cuda(), torch.from_numpy(g["view_rect"]).cuda(), int(brow[:, 1].max()))
+    assert np.array_equal(out.cpu().numpy(), g["views"])
+
+
+@pytest.mark.gpu
+def test_hue_kernel_over_all_colours_and_shifts():
+    """rgb -> hsv -> +shift -> rgb for every one of the 2^24 colours at several shifts, against the oracle (which equals
+    Pillow's Convert.c over all colours, see the CPU test)."""
+    from cp2_amd import ops
+    v = np.arange(256, dtype=np.uint8)
+    allc = np.stack(np.meshgrid(v, v, v, indexing="ij"), -1).reshape(16, 1024, 1024, 3)
+    packed = torch.from_numpy(_pack(allc)).cuda()
+    for hue in (0.0, 0.1, -0.1, 0.037):
+        x = packed.clone()
+        ops.color_ops(x, torch.from_numpy(np.stack([_colour_row((3,), hue=hue)] * 16)).cuda())
+        got = _unpack(x)
+        for b in range(0, 16, 5):
+            assert np.array_equal(got[b], P.adjust_hue(allc[b], hue)), (hue, b)
+
+
+@pytest.mark.gpu
+def test_kernels_vs_oracle_at_training_size():
+    """224 x 224 views from 300 x 400 sources (antialiased down-scaling: 5-7 taps), every adjustment order that puts the
+    contrast step first / in the middle / last, blur radii 0 and 1, erase rectangles."""
+    from cp2_amd import ops
+    rng = np.random.default_rng(11)
+    N, Hs, Ws, H, W, B = 6, 300, 400, 224, 224, 12
+    src = rng.integers(0, 256, (N, Hs, Ws, 3), dtype=np.uint8)
+    src[:3] = np.stack([P.gaussian_blur(s, 3.0) for s in src[:3]])                      # some smooth images
+    planar = torch.from_numpy(np.ascontiguousarray(src.transpose(0, 3, 1, 2))).cuda()
+    idx = rng.integers(0, N, B)
+    boxes = A.rrc_params(rng, B, Hs, Ws)
+    boxes[0] = (0, 0, Hs, Ws)
+    boxes[1] = (10, 20, 224, 224)                                                       # no resampling at all
+    boxes[2] = (10, 20, 100, 224)                                                       # vertical pass only
+    flips = rng.random(B) < 0.5
+    colour = A.jitter_table(rng, B, p=1.0, p_gray=0.3)
+    colour[3, :4] = (1, 3, 0, 2)
+    colour[4, :4] = (0, 2, 3, 1)
+    colour[5, :4] = -1
+    blur, rmax = A.blur_table(rng, B, p=0.7)
+    sig = {}
+    rects = A.erase_params(rng, B, H, W)
+    tab = torch.from_numpy(A.crop_table(idx, boxes, flips)).cuda()
+    rgbx = ops.pil_resize_crop(planar, tab, H, W)
+    resized = _unpack(rgbx)
+    ops.color_ops(rgbx, torch.from_numpy(colour).cuda())
+    coloured = _unpack(rgbx)
+    out = ops.blur_to_tensor(rgbx, torch.from_numpy(blur).cuda(), torch.from_numpy(rects).cuda(), rmax).cpu().numpy()
+    for b in range(B):
+        want = P.pil_crop_resize(src[idx[b]], boxes[b], H, W)
+        if flips[b]:
+            want = want[:, ::-1]
+        assert np.array_equal(resized[b], want), ("resize", b)
+        order = [int(k) for k in colour[b, :4] if k >= 0]
+        f = colour[b, 4:7].copy().view(np.float32)
+        for k in order:
+            want = P.adjust_hue_shift(want, int(colour[b, 7])) if k == 3 else P.JITTER_OPS[k](want, float(f[k]))
+        if colour[b, 8]:
+            want = P.to_grayscale3(want)
+        assert np.array_equal(coloured[b], want), ("colour", b, order)
+        if blur[b, 0]:
+            want = P.box_blur3(want, int(blur[b, 1]), int(blur[b, 2]), int(blur[b, 3]))
+        t = P.to_tensor(want).copy()
+        et, el, eh, ew = rects[b]
+        t[:, et:et + eh, el:el + ew] = 0.0
+        assert np.array_equal(out[b], t), ("blur/tensor", b)
+
+
+@pytest.mark.gpu
+def test_foreground_uint8_view_and_blur_radius_guard():
+    """The foreground crop's uint8 view (fp32 half-pixel bilinear rounded half up -- the oracle's stated rule; cv2's own
+    arithmetic is unpinned) and the argument checks of the blur entry."""
+    from cp2_amd import _lib, ops
+    rng = np.random.default_rng(2)
+    N, Hs, Ws, H, W, B = 3, 50, 61, 40, 44, 6
+    src = rng.integers(0, 256, (N, 3, Hs, Ws), dtype=np.uint8)
+    idx, boxes, flips = rng.integers(0, N, B), A.rrc_params(rng, B, Hs, Ws), rng.random(B) < 0.5
+    tab = torch.from_numpy(A.crop_table(idx, boxes, flips)).cuda()
+    rgbx = torch.empty((B, H, W), dtype=torch.int32, device="cuda")
+    img, pix, reg = ops.crop_resize_flip(torch.from_numpy(src).cuda(), None, tab, H, W, 1, want_f32=False, out_rgbx=rgbx)
+    assert img is None
+    for b in range(B):
+        want, want_pix, _ = O.crop_resize_flip(src[idx[b]].astype(np.float32) / np.float32(255.0), None, boxes[b], bool(flips[b]), H, W)
+        assert np.array_equal(_unpack(rgbx)[b], O.quantize_u8(want)), b
+        assert np.array_equal(pix[b].cpu().numpy(), want_pix)
+    with pytest.raises(_lib.Cp2LibraryError):
+        ops.blur_to_tensor(rgbx, torch.zeros((B, 4), dtype=torch.int32, device="cuda"), None, 99)
