@@ -18,10 +18,12 @@ SIGNATURES = {
     "cp2_error_string": [c_int],
     "cp2_profile_next_launch": [_P, _P],
     "cp2_compose_mask": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
+    "cp2_compose_pair": [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "cp2_strided_gather_f32": [_P, _P, c_int, c_int, c_int, c_int, _P],
     "cp2_strided_gather_i64": [_P, _P, c_int, c_int, c_int, c_int, _P],
     "cp2_gather_rows_f32": [_P, _P, _P, c_int, c_int, c_int64, _P, _P],
     "cp2_corr_iou": [_P, _P, _P, _P, _P, _P, c_int, c_int, _P],
+    "cp2_corr_iou_strided": [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "cp2_ema_flat": [_P, _P, c_int64, c_float, c_float, _P],
     "cp2_ema_flat_timed": [_P, _P, c_int64, c_float, c_float, _P, _P, _P],
     "cp2_ema_flat_shadow": [_P, _P, _P, c_int64, c_float, c_float, _P, _P, _P],
@@ -31,6 +33,11 @@ SIGNATURES = {
     "cp2_pool_finalize": [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
     "cp2_pool_bwd": [_P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, _P],
     "cp2_feat_bwd": [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int64, c_int, c_int, c_int, _P],
+    "cp2_feat_normalize_pool_pair": [_P, c_int64, c_int64, c_int64, _P, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P,
+                                     c_int, c_int, c_int, _P],
+    "cp2_feat_bwd_fused": [_P, _P, _P, _P, c_int, c_int64, _P, _P, c_int, _P, _P, _P, _P, _P, c_int, _P, c_int64, c_int64, c_int64,
+                           c_int, c_int, c_int, _P],
+    "cp2_step_scalars": [_P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, c_float, _P, c_int, c_int, _P],
     "cp2_rowkey_num_splits": [c_int, c_int],
     "cp2_rowkey_infonce_fwd": [_P, c_int, c_int64, c_int64, c_int64, c_int, _P, c_int, _P, c_int, c_float,
                                c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, c_int, _P],
@@ -57,7 +64,7 @@ SIGNATURES = {
     "cp2_bn_bwd": [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, _P],
     "cp2_masked_quantiles": [_P, c_int64, c_int64, c_int, c_int, _P, _P, c_int, c_int, _P, c_int, _P, _P, c_int64, _P],
     "cp2_quantiles_workspace_bytes": [c_int, _P, _P, c_int],
-    "cp2_masked_quantiles_multi": [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, c_int64, _P],
+    "cp2_masked_quantiles_multi": [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int64, _P],
     "cp2_maxpool3s2_fwd": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "cp2_maxpool3s2_bwd": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "cp2_cutpaste": [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],

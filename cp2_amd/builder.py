@@ -9,7 +9,7 @@ as a hand-written gfx950 kernel from libcp2hip.so:
     :557-567   EMA python loop (~600 launches)     ops.ema_flat over flat parameter buffers (1 launch)
     :609-649   shuffle-BN gather / scatter         dist.concat_all_gather + ops.gather_rows
     :1261-1292, 1392-1448  normalise, pool, dense + instance InfoNCE, backward
-                                                   functional.cp2_loss_section (f32 MFMA, 9 launches)
+                                                   functional.cp2_loss_section (f32 MFMA, 10 launches)
     :569-587   enqueue (host sync on the pointer)  ops.enqueue (pointer stays on the device)
 
 The encoders (ResNet + ASPP/FCN head) stay in PyTorch-ROCm.  There is no CPU path: forward()
@@ -188,6 +188,44 @@ class _CommTimer:
             t1.record()
             self.sink.setdefault(self.name, []).append((self.t0, t1))
         return False
+
+
+def _rows_as_f32(x: torch.Tensor):
+    """(rows, restore): a dense [B, ...] tensor (NCHW or channels-last, fp32 or bf16) as a [B, n] float32 matrix that
+    shares its memory -- what the row gathers and the row exchange move -- and the function that gives a matrix of that
+    shape back the tensor's shape, strides and dtype."""
+    B = x.shape[0]
+    cl = x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
+    flat = (x.permute(0, 2, 3, 1) if cl else x).reshape(B, -1)
+    shape, dtype = x.shape, x.dtype
+    if dtype != torch.float32:
+        if (flat.shape[1] * flat.element_size()) % 4:
+            raise ValueError("row size is not a multiple of 4 bytes")
+        flat = flat.view(torch.float32)
+
+    def restore(rows: torch.Tensor) -> torch.Tensor:
+        r = rows if dtype == torch.float32 else rows.view(dtype)
+        if cl:
+            return r.reshape(rows.shape[0], shape[2], shape[3], shape[1]).permute(0, 3, 1, 2)
+        return r.reshape((rows.shape[0],) + tuple(shape[1:]))
+    return flat, restore
+
+
+# (log name, index into the cp2_step_scalars vector); the reference's wandb scalar names (builder.py:1553-1604)
+_CP2_LOG_NAMES = (("train/loss_step", CF.S_LOSS), ("train/loss_ins_step", CF.S_LOSS_INS), ("train/loss_dense_step", CF.S_LOSS_DENSE),
+                  ("train/acc_ins_step", CF.S_ACC1), ("train/acc_seg_step", CF.S_ACC_DENSE), ("train/+ive_scores_step", CF.S_POS_SCORE),
+                  ("train/-ive_scores_step", CF.S_NEG_SCORE), ("step/instance_average_positive_scores", CF.S_INS_POS),
+                  ("train/cross_image_variance_source_step", CF.S_VAR_SRC), ("train/cross_image_variance_target_step", CF.S_VAR_TGT))
+_CP2_LOG_NAMES_Q = _CP2_LOG_NAMES + (
+    ("step/dense_per_sample_average_positive_scores", CF.S_POS_SCORE),
+    ("step/dense_per_sample_lower_positive_scores", CF.S_DPOS_Q), ("step/dense_per_sample_median_positive_scores", CF.S_DPOS_Q + 1),
+    ("step/dense_per_sample_upper_positive_scores", CF.S_DPOS_Q + 2),
+    ("step/dense_per_sample_average_negative_scores", CF.S_NEG_SCORE),
+    ("step/dense_per_sample_lower_negative_scores", CF.S_DNEG_Q), ("step/dense_per_sample_median_negative_scores", CF.S_DNEG_Q + 1),
+    ("step/dense_per_sample_upper_negative_scores", CF.S_DNEG_Q + 2),
+    ("step/instance_average_negative_scores", CF.S_INS_NEG_MEAN),
+    ("step/instance_lower_negative_scores", CF.S_INS_Q), ("step/instance_median_negative_scores", CF.S_INS_Q + 1),
+    ("step/instance_upper_negative_scores", CF.S_INS_Q + 2))
 
 
 class MODEL(nn.Module):
@@ -524,47 +562,94 @@ class MODEL(nn.Module):
     def forward_cp2(self, img_a, img_b, bg0, bg1, visualize, step, new_epoch, pixel_ids_a, pixel_ids_b,
                     region_ids_a, region_ids_b, idx_shuffle=None):
         s = self.output_stride
-        b = img_a.shape[0]
-        img_a, _, mask_a = ops.compose_mask(img_a.contiguous(), bg0.contiguous(), s)
-        img_b, _, mask_b = ops.compose_mask(img_b.contiguous(), bg1.contiguous(), s)
+        b, _, H, W = img_a.shape
+        # ---- composition of both views in ONE launch, already in the layout / precision the stem convolution reads, the
+        # key view's rows already in the order the shuffle-BN exchange sends them (reference builder.py:1146-1159, :609-630)
+        multi = cdist.multi()
+        plan = idx_unshuffle = None
+        a2a = multi and self.shuffle_exchange == "all_to_all"
+        if a2a:
+            host = idx_shuffle.cpu() if idx_shuffle is not None else cdist.shared_permutation(b * cdist.world_size(), img_a.device)
+            plan = cdist.ShufflePlan(host, cdist.rank(), cdist.world_size())
+            row_b = plan.device_tables(img_a.device)[0]                    # send order
+        elif not multi:
+            if idx_shuffle is None:
+                idx_shuffle = cdist.make_shuffle_index(b, img_a.device)
+            idx_unshuffle = torch.argsort(idx_shuffle)
+            row_b = idx_shuffle.contiguous()
+        else:
+            row_b = None                                                   # the reference's all-gather form shuffles after the gather
+        fused = W % 4 == 0 and all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in (img_a, img_b, bg0, bg1))
+        if fused:
+            out_dtype = torch.bfloat16 if self.amp_dtype == torch.bfloat16 else torch.float32
+            img_a, img_b, mask_a, mask_b = ops.compose_pair(img_a, bg0, img_b, bg1, s, row_b, self.channels_last, out_dtype)
+        else:
+            img_a, _, mask_a = ops.compose_mask(img_a.contiguous(), bg0.contiguous(), s)
+            img_b, _, mask_b = ops.compose_mask(img_b.contiguous(), bg1.contiguous(), s)
+            if row_b is not None and not a2a:                # one rank: the shuffle is this gather; all-to-all: exchange_rows gathers
+                img_b = ops.gather_rows(img_b, row_b)
         mask_a, mask_b = mask_a.reshape(b, -1), mask_b.reshape(b, -1)
-        region_a = ops.strided_gather(region_ids_a.contiguous(), s).reshape(b, -1)
-        region_b = ops.strided_gather(region_ids_b.contiguous(), s).reshape(b, -1)
         ids = None
         weights = (float(self.lmbd_pixel_corr_weight), float(self.lmbd_region_corr_weight), float(self.lmbd_not_corr_weight))
         if weights != (1.0, 1.0, 1.0):
-            pixel_a = ops.strided_gather(pixel_ids_a.contiguous(), s).reshape(b, -1)
-            pixel_b = ops.strided_gather(pixel_ids_b.contiguous(), s).reshape(b, -1)
-            ids = (pixel_a, pixel_b, region_a, region_b)
-        iou, iou_masked = ops.corr_iou(region_a, region_b, mask_a, mask_b)      # logged per epoch, stays on device
+            ids = tuple(ops.strided_gather(t.contiguous(), s).reshape(b, -1) for t in (pixel_ids_a, pixel_ids_b, region_ids_a, region_ids_b))
+        # IoUs of the down-sampled region-id maps, read straight from the full-resolution maps (logged per epoch, on device)
+        iou, iou_masked = ops.corr_iou_strided(region_ids_a.contiguous(), region_ids_b.contiguous(), s, mask_a, mask_b)
         self.correlation_ious.append(iou)
         self.masked_correlation_ious.append(iou_masked)
         if len(self.correlation_ious) >= 1024:              # keep the python lists short (device-side concatenation, no sync)
             self.correlation_ious[:] = [torch.cat(self.correlation_ious)]
             self.masked_correlation_ious[:] = [torch.cat(self.masked_correlation_ious)]
 
-        # The key branch (EMA -> shuffle-BN all-gather -> key encoder -> un-shuffle all-gather) does not depend on the
-        # query encoder (reference order builder.py:1260-1277 is serial).  overlap_key_branch:
-        #   "gather" (default when world size > 1): EMA + the image all-gather and row gather run on a side HIP stream
-        #            and overlap the query forward; the key encoder itself follows on the main stream (two compute-heavy
-        #            branches interleaved on one GPU measured 4 % SLOWER than back to back);
+        # The key branch (EMA -> shuffle-BN exchange -> key encoder -> un-shuffle) does not depend on the query encoder
+        # (reference order builder.py:1260-1277 is serial).  overlap_key_branch:
+        #   "gather" (default when world size > 1): EMA + the image exchange run on a side HIP stream and overlap the query
+        #            forward; the key encoder itself follows on the main stream (two compute-heavy branches interleaved on
+        #            one GPU measured 4 % SLOWER than back to back);
         #   True: the whole key branch on the side stream;   False (default at world size 1): everything in order.
         self.flatten_parameters()        # on the main stream, before the fork: it re-homes the query parameters too
         self._refresh_query_shadow()
         cur = torch.cuda.current_stream()
         mode = self.overlap_key_branch
         if mode is None:
-            mode = "gather" if cdist.multi() else False
+            mode = "gather" if multi else False
         side = self._key_stream() if mode else cur
         if side is not cur:
             side.wait_stream(cur)
-        k = None
+
+        def exchange_in(x):
+            """This rank's composed key images -> the rows its key encoder takes."""
+            if a2a:
+                with self._comm("c1_image_exchange"):
+                    rows, restore = _rows_as_f32(x)
+                    return restore(cdist.exchange_rows(rows, plan, take=ops.gather_rows, presorted=fused))
+            if multi:
+                return self._batch_shuffle_ddp(x, idx_shuffle)
+            return x, None                                   # one rank: compose_pair wrote the rows in shuffled order
+
+        def exchange_out(k_enc, ctx):
+            """Key encoder outputs -> (tensor, row index) such that sample n's features are tensor[row[n]]."""
+            if a2a:
+                with self._comm("c3_key_unshuffle"):
+                    k32 = k_enc.float().contiguous()
+                    return cdist.exchange_rows(k32, plan, backward=True, take=ops.gather_rows, keep_order=True), \
+                        plan.device_tables(k32.device)[3]
+            if multi:
+                return self._batch_unshuffle_ddp(k_enc, ctx), None
+            return k_enc.float(), idx_unshuffle
+
+        k = k_row = None
         with torch.cuda.stream(side), torch.no_grad():
             if self.ema_in_forward:
                 self._momentum_update_key_encoder()
-            img_b, idx_unshuffle = self._batch_shuffle_ddp(img_b, idx_shuffle)
+            if side is not cur and img_b.is_cuda:
+                img_b.record_stream(side)
+            if a2a:
+                img_k, ctx = exchange_in(img_b), None
+            else:
+                img_k, ctx = exchange_in(img_b)
             if mode != "gather":
-                k = self._batch_unshuffle_ddp(self._encode_key(img_b), idx_unshuffle)
+                k, k_row = exchange_out(self._encode_key(img_k), ctx)
         q = self._encode(self.encoder_q, img_a).float()                          # queries: b x C x h x w
         if side is not cur:
             with self._comm("key_branch_wait_exposed"):       # main stream idle until EMA + image exchange are done
@@ -572,36 +657,19 @@ class MODEL(nn.Module):
         if k is None:
             with torch.no_grad():
                 if side is not cur:
-                    img_b.record_stream(cur)          # allocated on the side stream, read on this one
-                k = self._batch_unshuffle_ddp(self._encode_key(img_b), idx_unshuffle)
+                    img_k.record_stream(cur)          # allocated on the side stream, read on this one
+                k, k_row = exchange_out(self._encode_key(img_k), ctx)
 
         out = CF.cp2_loss_section(q, k, mask_a, mask_b, self.queue, temp_global=self.temp_global,
                                   temp_local=self.temp_local, lmbd_dense=self.lmbd_dense_loss,
                                   include_background=self.include_background, ids=ids, weights=weights,
                                   want_quartiles=self.log_quartiles, negative_type=self.negative_type.value,
-                                  negative_scale=self.negative_scale)
+                                  negative_scale=self.negative_scale, k_row=k_row)
         self._dequeue_and_enqueue(out.k_pos)
-        logs = {"train/loss_step": out.loss.detach(), "train/loss_ins_step": out.loss_instance,
-                "train/loss_dense_step": out.loss_dense, "train/acc_ins_step": out.acc1,
-                "train/acc_seg_step": out.acc_dense,
-                "train/+ive_scores_step": out.dense_sample[:, 3].mean(),
-                "train/-ive_scores_step": out.dense_sample[:, 4].mean(),
-                "step/instance_average_positive_scores": out.instance_pos.mean(),
-                # builder.py:1265,1282: spread of the pooled foreground vectors over the batch (unbiased std, channel mean)
-                "train/cross_image_variance_source_step": out.q_pos.std(0).mean(),
-                "train/cross_image_variance_target_step": out.k_pos.std(0).mean()}
-        if self.log_quartiles:           # same scalar names as the reference's wandb.log (builder.py:1589-1601)
-            pq, nq, iq = out.dense_pos_quartiles.mean(1), out.dense_neg_quartiles.mean(1), out.instance_neg_quartiles.mean(1)
-            logs.update({"step/dense_per_sample_average_positive_scores": logs["train/+ive_scores_step"],
-                         "step/dense_per_sample_lower_positive_scores": pq[0], "step/dense_per_sample_median_positive_scores": pq[1],
-                         "step/dense_per_sample_upper_positive_scores": pq[2],
-                         "step/dense_per_sample_average_negative_scores": logs["train/-ive_scores_step"],
-                         "step/dense_per_sample_lower_negative_scores": nq[0], "step/dense_per_sample_median_negative_scores": nq[1],
-                         "step/dense_per_sample_upper_negative_scores": nq[2],
-                         "step/instance_average_negative_scores": out.instance_neg_mean.mean(),
-                         "step/instance_lower_negative_scores": iq[0], "step/instance_median_negative_scores": iq[1],
-                         "step/instance_upper_negative_scores": iq[2]})
-        self._log_step(step, b, logs)
+        # the logged scalars come out of the loss section as one device vector (cp2_step_scalars); names as the
+        # reference's wandb.log (builder.py:1553-1604)
+        names = _CP2_LOG_NAMES_Q if self.log_quartiles else _CP2_LOG_NAMES
+        self._log_vector(step, b, names, out.scalars)
         if new_epoch:
             self.epoch += 1
         return out.loss
@@ -699,18 +767,35 @@ class MODEL(nn.Module):
         if len(self._pending_logs) >= limit and not torch.cuda.is_current_stream_capturing():
             self.flush_logs()
 
+    def _log_vector(self, step, n, names, vec):
+        """A record whose values already sit in one device vector: names = ((log name, index into vec), ...)."""
+        self._pending_logs.append((step, n, names, vec))
+        limit = self.sync_logs_every or 4096
+        if len(self._pending_logs) >= limit and not torch.cuda.is_current_stream_capturing():
+            self.flush_logs()
+
     def flush_logs(self):
         if not self._pending_logs:
             return []
-        vals = torch.stack([p[3] for p in self._pending_logs]).cpu().tolist() if \
-            len({len(p[2]) for p in self._pending_logs}) == 1 else [p[3].cpu().tolist() for p in self._pending_logs]
+        # one device -> host copy for everything queued: records of equal length are stacked first
+        by_len = {}
+        for i, p in enumerate(self._pending_logs):
+            by_len.setdefault(p[3].numel(), []).append(i)
+        rows = [None] * len(self._pending_logs)
+        for idxs in by_len.values():
+            block = torch.stack([self._pending_logs[i][3].detach().float() for i in idxs]).cpu().tolist()
+            for i, r in zip(idxs, block):
+                rows[i] = r
         meters = {"train/loss_step": self.loss_o, "train/loss_ins_step": self.loss_i, "train/loss_dense_step": self.loss_d,
                   "train/acc_ins_step": self.acc_ins, "train/acc_seg_step": self.acc_seg,
                   "train/cross_image_variance_source_step": self.cross_image_variance_source,
                   "train/cross_image_variance_target_step": self.cross_image_variance_target}
         out = []
-        for (step, n, names, _), row in zip(self._pending_logs, vals):
-            rec = dict(zip(names, row))
+        for (step, n, names, _), row in zip(self._pending_logs, rows):
+            if names and isinstance(names[0], tuple):          # (name, index) pairs into a scalar vector
+                rec = {k: row[i] for k, i in names}
+            else:
+                rec = dict(zip(names, row))
             for k, meter in meters.items():
                 if k in rec:
                     meter.update(rec[k], n)

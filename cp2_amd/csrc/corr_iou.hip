@@ -13,7 +13,7 @@ __global__ __launch_bounds__(1024) void corr_iou_kernel(const int64_t* __restric
                                                         const float* __restrict__ mask_a,
                                                         const float* __restrict__ mask_b,
                                                         float* __restrict__ iou, float* __restrict__ iou_masked,
-                                                        int P, int N2) {
+                                                        int P, int N2, int H, int W, int stride, int Ws) {
     extern __shared__ __attribute__((aligned(16))) float keys[];
     __shared__ int red[2][16];
     const int n = blockIdx.x;
@@ -21,15 +21,22 @@ __global__ __launch_bounds__(1024) void corr_iou_kernel(const int64_t* __restric
     float* out = masked ? iou_masked : iou;
     if (!out) return;
     const int nvalid = 2 * P + 1;
+    // stride > 0: the id maps are the full-resolution [H, W] ones and element p of the P = Hs x Ws grid is their centre
+    // tap (s/2 + s * (p / Ws), s/2 + s * (p % Ws)) -- reference builder.py:1155-1186 slices first, then compares
+    auto at = [&](int p) -> int64_t {
+        if (stride <= 0) return (int64_t)n * P + p;
+        const int off = stride >> 1;
+        return ((int64_t)n * H + off + (int64_t)stride * (p / Ws)) * W + off + (int64_t)stride * (p % Ws);
+    };
     for (int i = threadIdx.x; i < N2; i += blockDim.x) {
         float v = INFINITY;  // padding sorts behind every real key
         if (i == 0) {
             v = 0.0f;
         } else if (i <= P) {
-            const float idf = (float)(ids_a[(int64_t)n * P + (i - 1)] + 1);
+            const float idf = (float)(ids_a[at(i - 1)] + 1);
             v = masked ? __fmul_rn(idf, mask_a[(int64_t)n * P + (i - 1)]) : idf;
         } else if (i < nvalid) {
-            const float idf = (float)(ids_b[(int64_t)n * P + (i - 1 - P)] + 1);
+            const float idf = (float)(ids_b[at(i - 1 - P)] + 1);
             v = masked ? __fmul_rn(idf, mask_b[(int64_t)n * P + (i - 1 - P)]) : idf;
         }
         keys[i] = v;
@@ -70,8 +77,8 @@ __global__ __launch_bounds__(1024) void corr_iou_kernel(const int64_t* __restric
     }
 }
 
-CP2_API int cp2_corr_iou(const int64_t* ids_a, const int64_t* ids_b, const float* mask_a, const float* mask_b,
-                         float* iou, float* iou_masked, int B, int P, void* stream) {
+static int corr_iou_launch(const int64_t* ids_a, const int64_t* ids_b, const float* mask_a, const float* mask_b, float* iou,
+                           float* iou_masked, int B, int P, int H, int W, int stride, int Ws, void* stream) {
     if (!ids_a || !ids_b) return CP2_ERR_NULL;
     if (!iou && !iou_masked) return CP2_ERR_NULL;
     if (iou_masked && (!mask_a || !mask_b)) return CP2_ERR_NULL;
@@ -87,6 +94,20 @@ CP2_API int cp2_corr_iou(const int64_t* ids_a, const int64_t* ids_b, const float
     }
     const int threads = N2 >= 2048 ? 1024 : (N2 / 2 < 64 ? 64 : N2 / 2);
     hipLaunchKernelGGL(corr_iou_kernel, dim3(B, 2), dim3(threads), lds, cp2_stream(stream), ids_a, ids_b, mask_a,
-                       mask_b, iou, iou_masked, P, N2);
+                       mask_b, iou, iou_masked, P, N2, H, W, stride, Ws);
     return cp2_launch_status();
+}
+
+CP2_API int cp2_corr_iou(const int64_t* ids_a, const int64_t* ids_b, const float* mask_a, const float* mask_b,
+                         float* iou, float* iou_masked, int B, int P, void* stream) {
+    return corr_iou_launch(ids_a, ids_b, mask_a, mask_b, iou, iou_masked, B, P, 0, 0, 0, 1, stream);
+}
+
+// The same with the centre-tap down-sampling of the id maps folded in: ids are [B,H,W], the masks already [B,Hs*Ws].
+CP2_API int cp2_corr_iou_strided(const int64_t* ids_a, const int64_t* ids_b, const float* mask_a, const float* mask_b,
+                                 float* iou, float* iou_masked, int B, int H, int W, int stride, void* stream) {
+    if (H <= 0 || W <= 0 || stride <= 0) return CP2_ERR_SHAPE;
+    const int off = stride / 2, Hs = (H - off + stride - 1) / stride, Ws = (W - off + stride - 1) / stride;
+    if (Hs <= 0 || Ws <= 0) return CP2_ERR_SHAPE;
+    return corr_iou_launch(ids_a, ids_b, mask_a, mask_b, iou, iou_masked, B, Hs * Ws, H, W, stride, Ws, stream);
 }

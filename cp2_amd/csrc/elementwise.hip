@@ -96,6 +96,122 @@ CP2_API int cp2_compose_mask(const float* img, const float* bg, float* out_img, 
 }
 
 // ---------------------------------------------------------------------------
+// compose_pair: both views of the step in ONE launch (reference builder.py:1146-1159 runs the composition once per
+// view), with what the training step did in separate launches afterwards folded in:
+//   * the key view's rows can be written in shuffle-BN order (out_b[j] = compose(img_b[row_b[j]], bg1[row_b[j]]),
+//     reference builder.py:630 applies the same permutation as a gather after the composition) -- the gather launch and
+//     its 2 x 19 MB of traffic disappear; the down-sampled mask stays in the ORIGINAL row order (the loss needs it there);
+//   * the output can be written channels-last and / or in bf16 -- the layout copy and the autocast cast kernel in front
+//     of the stem convolution disappear; bf16 is the round-to-nearest-even of the very fp32 value the fp32 path stores.
+// One thread = 4 consecutive pixels of one row (W % 4 == 0), all three channels.
+// ---------------------------------------------------------------------------
+struct ComposePairArgs {
+    const float* img[2]; const float* bg[2];
+    void* out[2];                    // [B,3,H,W] logical; memory NCHW or NHWC, fp32 or bf16
+    float* mask_ds[2];               // [B,Hs,Ws] each (may be NULL)
+    const int64_t* row_b;            // device int64 [B] or NULL: source row of output row j of view b
+    int B, H, W, stride, Hs, Ws, nhwc, bf16;
+};
+
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);     // NaN stays NaN (quiet)
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+__global__ __launch_bounds__(256) void compose_pair_kernel(ComposePairArgs a) {
+    const int64_t plane = (int64_t)a.H * a.W;
+    const int wv = a.W / 4;
+    const int64_t per_view = (int64_t)a.B * a.H * wv;
+    const int off = a.stride >> 1;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < 2 * per_view; t += (int64_t)gridDim.x * blockDim.x) {
+        const int view = t >= per_view;
+        const int64_t tt = view ? t - per_view : t;
+        const int xg = (int)(tt % wv), y = (int)((tt / wv) % a.H), j = (int)(tt / ((int64_t)wv * a.H));
+        const int x0 = xg * 4;
+        int b = j;                                               // source row
+        if (view && a.row_b) {
+            const int64_t r = a.row_b[j];
+            b = (r < 0 || r >= a.B) ? j : (int)r;                // a bad index cannot fault; tests check the permutation
+        }
+        const int64_t base = (int64_t)b * 3 * plane + (int64_t)y * a.W + x0;
+        float bgv[3][4], o[3][4], m[4];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float4 g = *reinterpret_cast<const float4*>(a.bg[view] + base + c * plane);
+            bgv[c][0] = g.x, bgv[c][1] = g.y, bgv[c][2] = g.z, bgv[c][3] = g.w;
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) m[v] = (bgv[0][v] == 0.0f) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float4 i4 = *reinterpret_cast<const float4*>(a.img[view] + base + c * plane);
+            o[c][0] = __fadd_rn(__fmul_rn(i4.x, m[0]), bgv[c][0]), o[c][1] = __fadd_rn(__fmul_rn(i4.y, m[1]), bgv[c][1]);
+            o[c][2] = __fadd_rn(__fmul_rn(i4.z, m[2]), bgv[c][2]), o[c][3] = __fadd_rn(__fmul_rn(i4.w, m[3]), bgv[c][3]);
+        }
+        const int64_t obase = (int64_t)j * 3 * plane;            // output row j
+        if (!a.nhwc) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int64_t e = obase + c * plane + (int64_t)y * a.W + x0;
+                if (a.bf16) {
+                    ushort4 q{f32_to_bf16_rne(o[c][0]), f32_to_bf16_rne(o[c][1]), f32_to_bf16_rne(o[c][2]), f32_to_bf16_rne(o[c][3])};
+                    *reinterpret_cast<ushort4*>(static_cast<unsigned short*>(a.out[view]) + e) = q;
+                } else {
+                    *reinterpret_cast<float4*>(static_cast<float*>(a.out[view]) + e) = make_float4(o[c][0], o[c][1], o[c][2], o[c][3]);
+                }
+            }
+        } else {
+            const int64_t e = obase + ((int64_t)y * a.W + x0) * 3;   // 12 consecutive values: pixel-major, channel-minor
+            float lin[12];
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) lin[v * 3 + c] = o[c][v];
+            if (a.bf16) {
+                unsigned short* d = static_cast<unsigned short*>(a.out[view]) + e;       // 24 bytes, 8-byte aligned
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    *reinterpret_cast<ushort4*>(d + 4 * k) = ushort4{f32_to_bf16_rne(lin[4 * k]), f32_to_bf16_rne(lin[4 * k + 1]),
+                                                                      f32_to_bf16_rne(lin[4 * k + 2]), f32_to_bf16_rne(lin[4 * k + 3])};
+            } else {
+                float* d = static_cast<float*>(a.out[view]) + e;                         // 48 bytes, 16-byte aligned
+#pragma unroll
+                for (int k = 0; k < 3; ++k) *reinterpret_cast<float4*>(d + 4 * k) = make_float4(lin[4 * k], lin[4 * k + 1], lin[4 * k + 2], lin[4 * k + 3]);
+            }
+        }
+        float* md = a.mask_ds[view];
+        if (md && y >= off && (y - off) % a.stride == 0) {
+            const int ys = (y - off) / a.stride;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int x = x0 + v;
+                if (x >= off && (x - off) % a.stride == 0) md[((int64_t)b * a.Hs + ys) * a.Ws + (x - off) / a.stride] = m[v];
+            }
+        }
+    }
+}
+
+CP2_API int cp2_compose_pair(const float* img_a, const float* bg0, const float* img_b, const float* bg1, void* out_a, void* out_b,
+                             float* mask_ds_a, float* mask_ds_b, const int64_t* row_b, int B, int H, int W, int stride,
+                             int channels_last, int out_bf16, void* stream) {
+    if (!img_a || !bg0 || !img_b || !bg1 || !out_a || !out_b) return CP2_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || ((mask_ds_a || mask_ds_b) && stride <= 0)) return CP2_ERR_SHAPE;
+    if (W % 4) return CP2_ERR_UNSUPPORTED;                        // the per-view entry cp2_compose_mask takes any width
+    if (!cp2_aligned16(img_a) || !cp2_aligned16(bg0) || !cp2_aligned16(img_b) || !cp2_aligned16(bg1) || !cp2_aligned16(out_a) ||
+        !cp2_aligned16(out_b))
+        return CP2_ERR_ALIGN;
+    if (stride <= 0) stride = 1;
+    ComposePairArgs a{{img_a, img_b}, {bg0, bg1}, {out_a, out_b}, {mask_ds_a, mask_ds_b}, row_b, B, H, W, stride,
+                      ds_size(H, stride), ds_size(W, stride), channels_last != 0, out_bf16 != 0};
+    int blocks = cp2_cdiv((int64_t)2 * B * H * (W / 4), 256);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(compose_pair_kernel, dim3(blocks), dim3(256), 0, cp2_stream(stream), a);
+    return cp2_launch_status();
+}
+
+// ---------------------------------------------------------------------------
 // strided gather: y[b,i,j] = x[b, s/2+s*i, s/2+s*j]   (builder.py:1155-1186)
 // ---------------------------------------------------------------------------
 template <typename T>

@@ -1021,6 +1021,85 @@ __global__ __launch_bounds__(256) void dense_finalize_kernel(DenseArgs a, float*
     }
 }
 
+// dense_merge_kernel + dense_finalize_kernel in one launch (round 3): one workgroup per sample folds the S partial column
+// statistics of its own key pixels (same operations, same order as dense_merge_kernel), stores the merged per-key
+// values the backward and the callers read, and finishes the sample's scalars from them.
+__global__ __launch_bounds__(256) void dense_post_kernel(DenseArgs a, float* __restrict__ sample_scal, int64_t BP) {
+    __shared__ float red[6][4];
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    const int n = blockIdx.x, P = a.P, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int S = a.splits;
+    const int64_t arr = (int64_t)S * BP;
+    float sa = 0.f, sb = 0.f, t_lse = 0.f, t_a = 0.f, t_pos = 0.f, t_all = 0.f, best = -INFINITY;
+    int64_t best_flat = 0;
+    for (int y = tid; y < P; y += 256) {
+        const int64_t o = (int64_t)n * P + y;
+        float lse, ca, pos, all, cmax;
+        int ax;
+        if (S > 1) {
+            const float* q = a.part + o;
+            float M = -INFINITY;
+            for (int sp = 0; sp < S; ++sp) M = fmaxf(M, q[(int64_t)sp * BP]);
+            float s = 0.f;
+            ca = 0.f, pos = 0.f, all = 0.f, cmax = -INFINITY, ax = 0;
+            for (int sp = 0; sp < S; ++sp) {
+                const float* e = q + (int64_t)sp * BP;
+                const float m = e[0];
+                if (m > -INFINITY) s += e[arr] * __expf(m - M);
+                ca += e[2 * arr]; pos += e[3 * arr]; all += e[4 * arr];
+                const float v = e[5 * arr];
+                if (v > cmax) { cmax = v; ax = __float_as_int(e[6 * arr]); }
+            }
+            lse = M + logf(s);
+            a.lse[o] = lse, a.colsum_a[o] = ca, a.possum[o] = pos, a.allsum[o] = all, a.colmax[o] = cmax, a.argx[o] = ax;
+        } else {
+            lse = a.lse[o], ca = a.colsum_a[o], pos = a.possum[o], all = a.allsum[o], cmax = a.colmax[o], ax = a.argx[o];
+        }
+        const float mb = a.mask_b[o];
+        sa += a.mask_a[o];
+        sb += mb;
+        t_lse += mb * lse;
+        t_a += mb * ca;
+        t_pos += mb * pos;
+        t_all += all;
+        const int64_t flat = (int64_t)ax * P + y;
+        if (cmax > best || (cmax == best && flat < best_flat)) { best = cmax; best_flat = flat; }
+    }
+    float vals[6] = {sa, sb, t_lse, t_a, t_pos, t_all};
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const float s = wave_sum(vals[j]);
+        if (lane == 0) red[j][w] = s;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const int64_t of = __shfl_xor(best_flat, off, 64);
+        if (ov > best || (ov == best && of < best_flat)) { best = ov; best_flat = of; }
+    }
+    if (lane == 0) { bv[w] = best; bi[w] = (int)best_flat; }
+    __syncthreads();
+    if (tid == 0) {
+        float t[6];
+        for (int j = 0; j < 6; ++j) t[j] = red[j][0] + red[j][1] + red[j][2] + red[j][3];
+        float bb = bv[0];
+        int bf = bi[0];
+        for (int j = 1; j < 4; ++j)
+            if (bv[j] > bb || (bv[j] == bb && bi[j] < bf)) { bb = bv[j]; bf = bi[j]; }
+        const float Sa = t[0], Sb = t[1], npos = Sa * Sb;
+        float* o = sample_scal + (int64_t)n * 8;
+        o[0] = Sa;
+        o[1] = Sb;
+        o[2] = (Sa * t[2] - t[3]) / npos;                 // 0/0 = NaN when a mask is empty, as the reference
+        o[3] = t[4] / npos;
+        o[4] = (t[5] - t[4]) / ((float)P * (float)P - npos);
+        o[5] = a.mask_a[(int64_t)n * P + bf / P] * a.mask_b[(int64_t)n * P + bf % P];
+        o[6] = 0.f;
+        o[7] = 0.f;
+    }
+}
+
 // out[0] = mean_n scal[n][2] (dense loss), out[1] = 100 * mean_n scal[n][5] (arg-max accuracy)
 __global__ __launch_bounds__(64) void dense_batch_kernel(const float* __restrict__ scal, int B, float* __restrict__ out) {
     float l = 0.f, c = 0.f;
@@ -1149,7 +1228,7 @@ CP2_API int cp2_dense_infonce_fwd(const float* q_dense, const float* k_dense, co
                                   const float* negative_center, int B, int C, int P, void* stream) {
     int rc = dense_check(q_dense, k_dense, mask_a, mask_b, pix_a, pix_b, reg_a, reg_b, B, C, P, temperature);
     if (rc) return rc;
-    if (!lse || !colsum_a || !possum || !allsum || !colmax || !argx || !sample_scal || !batch_out) return CP2_ERR_NULL;
+    if (!lse || !colsum_a || !possum || !allsum || !colmax || !argx || !sample_scal) return CP2_ERR_NULL;
     const int S = split_ws ? cp2_dense_num_splits(B, P) : 1;
     DenseArgs a{q_dense, k_dense, mask_a, mask_b, pix_a, pix_b, reg_a, reg_b, w_pixel, w_region, w_not,
                 1.0f / temperature, P, lse, colsum_a, possum, allsum, colmax, argx, logits_out, nullptr, 0.f, nullptr,
@@ -1163,15 +1242,9 @@ CP2_API int cp2_dense_infonce_fwd(const float* q_dense, const float* k_dense, co
     else CP2_LAUNCH_PROFILED((dense_fwd_kernel<false, false>), grid, dim3(DNT), lds, cp2_stream(stream), a);
     rc = cp2_launch_status();
     if (rc) return rc;
-    if (S > 1) {
-        const int64_t BP = (int64_t)B * P;
-        hipLaunchKernelGGL(dense_merge_kernel, dim3((unsigned)((BP + 255) / 256)), dim3(256), 0, cp2_stream(stream), a, BP);
-        rc = cp2_launch_status();
-        if (rc) return rc;
-    }
-    hipLaunchKernelGGL(dense_finalize_kernel, dim3(B), dim3(256), 0, cp2_stream(stream), a, sample_scal);
+    hipLaunchKernelGGL(dense_post_kernel, dim3(B), dim3(256), 0, cp2_stream(stream), a, sample_scal, (int64_t)B * P);
     rc = cp2_launch_status();
-    if (rc) return rc;
+    if (rc || !batch_out) return rc;                       // batch_out NULL: the caller forms the batch means (cp2_step_scalars)
     hipLaunchKernelGGL(dense_batch_kernel, dim3(1), dim3(64), 0, cp2_stream(stream), sample_scal, B, batch_out);
     return cp2_launch_status();
 }
@@ -1185,8 +1258,9 @@ CP2_API int cp2_dense_infonce_bwd(const float* q_dense, const float* k_dense, co
                                   void* stream) {
     int rc = dense_check(q_dense, k_dense, mask_a, mask_b, pix_a, pix_b, reg_a, reg_b, B, C, P, temperature);
     if (rc) return rc;
-    if (!lse || !sample_scal || !g_dense) return CP2_ERR_NULL;
+    if (!lse || !sample_scal) return CP2_ERR_NULL;
     const int S = split_ws ? cp2_dense_num_splits(B, P) : 1;
+    if (!g_dense && S == 1) return CP2_ERR_NULL;           // g_dense NULL: leave the S partial gradients in split_ws (cp2_feat_bwd_fused adds them)
     DenseArgs a{q_dense, k_dense, mask_a, mask_b, pix_a, pix_b, reg_a, reg_b, w_pixel, w_region, w_not,
                 1.0f / temperature, P, const_cast<float*>(lse), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                 sample_scal, grad_scale, g_dense, S, split_ws, negative_scale, negative_center};
@@ -1198,7 +1272,7 @@ CP2_API int cp2_dense_infonce_bwd(const float* q_dense, const float* k_dense, co
     } else if (pix_a) CP2_LAUNCH_PROFILED((dense_bwd_kernel<true, false>), grid, dim3(DNT), lds, cp2_stream(stream), a);
     else CP2_LAUNCH_PROFILED((dense_bwd_kernel<false, false>), grid, dim3(DNT), lds, cp2_stream(stream), a);
     rc = cp2_launch_status();
-    if (rc || S == 1) return rc;
+    if (rc || S == 1 || !g_dense) return rc;
     const int64_t n = (int64_t)B * CH * P;
     hipLaunchKernelGGL(dense_grad_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cp2_stream(stream), split_ws,
                        g_dense, S, n);

@@ -36,6 +36,7 @@ struct QuantArgs {
     float* out;                                            // [NQ][R] (torch.quantile layout)
     int R;
     int chunks;                                            // ceil(N / QCHUNK)
+    float* mean_out;                                       // NULL, or [R]: mean of the row as torch's x.mean(1) (NaN if the row holds one); want < 0, row kernel only
 };
 
 __device__ __forceinline__ unsigned f2key(float f) {
@@ -467,8 +468,16 @@ __global__ __launch_bounds__(QT3) void quantiles_row_kernel(QuantJobs jobs) {
         }                                                                                                \
     }
 
-    // ---- pass 0: top 12 bits, one histogram for all quantiles (its total is n)
-    CP2_Q_FOREACH(atomicAdd(&hist0[f2key(v) >> 20], 1u);)
+    // ---- pass 0: top 12 bits, one histogram for all quantiles (its total is n); the row sum rides along
+    float lsum = 0.f;
+    CP2_Q_FOREACH(atomicAdd(&hist0[f2key(v) >> 20], 1u); lsum += v;)
+    __shared__ double sum_w[QT3 / 64];
+    if (a.mean_out) {
+        double ds = (double)lsum;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ds += __shfl_xor(ds, off, 64);
+        if ((tid & 63) == 0) sum_w[tid >> 6] = ds;
+    }
     __syncthreads();
     {
         const unsigned h0 = hist0[4 * tid], h1 = hist0[4 * tid + 1], h2 = hist0[4 * tid + 2], h3 = hist0[4 * tid + 3];
@@ -477,6 +486,11 @@ __global__ __launch_bounds__(QT3) void quantiles_row_kernel(QuantJobs jobs) {
         if (tid == QT3 - 1) sh_n = incl;
         __syncthreads();
         const unsigned n = sh_n;
+        if (a.mean_out && tid == 0) {
+            double t = 0;
+            for (int i = 0; i < QT3 / 64; ++i) t += sum_w[i];
+            a.mean_out[r] = (n == (unsigned)a.N) ? (float)(t / (double)a.N) : NAN;   // a NaN element makes torch's mean NaN
+        }
         if (n == 0) {
             if (tid < NQ) a.out[(int64_t)tid * a.R + r] = NAN;
             return;
@@ -562,6 +576,7 @@ static int quant_check(const QuantArgs& a) {
     if (a.R <= 0 || a.N <= 0 || a.NQ <= 0) return CP2_ERR_SHAPE;
     if (a.NQ > QMAX) return CP2_ERR_UNSUPPORTED;
     if (a.want >= 0 && (!a.mask_a || !a.mask_b || a.P <= 0 || (int64_t)a.P * a.P != a.N)) return CP2_ERR_SHAPE;
+    if (a.mean_out && (a.want >= 0 || a.N > QROW_MAX)) return CP2_ERR_UNSUPPORTED;
     return CP2_OK;
 }
 
@@ -638,18 +653,19 @@ CP2_API int cp2_masked_quantiles(const float* x, int64_t stride_row, int64_t str
                                  const float* mask_a, const float* mask_b, int P, int want, const float* q, int NQ,
                                  float* out, void* workspace, int64_t workspace_bytes, void* stream) {
     QuantJobs jobs{};
-    jobs.job[0] = QuantArgs{x, stride_row, stride_elem, N, mask_a, mask_b, P, want, q, NQ, out, R, 0};
+    jobs.job[0] = QuantArgs{x, stride_row, stride_elem, N, mask_a, mask_b, P, want, q, NQ, out, R, 0, nullptr};
     return quant_launch(jobs, 1, workspace, workspace_bytes, cp2_stream(stream));
 }
 
 CP2_API int cp2_masked_quantiles_multi(int njobs, const float* const* x, const int64_t* stride_row, const int64_t* stride_elem,
                                        const int* R, const int* N, const float* const* mask_a, const float* const* mask_b,
                                        const int* P, const int* want, const float* q, int NQ, float* const* out,
-                                       void* workspace, int64_t workspace_bytes, void* stream) {
+                                       float* const* mean_out, void* workspace, int64_t workspace_bytes, void* stream) {
     if (njobs <= 0 || njobs > QJOBS) return CP2_ERR_UNSUPPORTED;
     if (!x || !stride_row || !stride_elem || !R || !N || !mask_a || !mask_b || !P || !want || !out) return CP2_ERR_NULL;
     QuantJobs jobs{};
     for (int j = 0; j < njobs; ++j)
-        jobs.job[j] = QuantArgs{x[j], stride_row[j], stride_elem[j], N[j], mask_a[j], mask_b[j], P[j], want[j], q, NQ, out[j], R[j], 0};
+        jobs.job[j] = QuantArgs{x[j], stride_row[j], stride_elem[j], N[j], mask_a[j], mask_b[j], P[j], want[j], q, NQ, out[j], R[j], 0,
+                                mean_out ? mean_out[j] : nullptr};
     return quant_launch(jobs, njobs, workspace, workspace_bytes, cp2_stream(stream));
 }

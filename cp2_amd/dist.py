@@ -176,13 +176,17 @@ def _all_to_all_rows(x: torch.Tensor, n_out: int, out_counts: List[int], in_coun
 
 @torch.no_grad()
 def exchange_rows(x: torch.Tensor, plan: ShufflePlan, backward: bool = False,
-                  take: Callable[[torch.Tensor, torch.Tensor], torch.Tensor] = _index_rows) -> torch.Tensor:
+                  take: Callable[[torch.Tensor, torch.Tensor], torch.Tensor] = _index_rows, presorted: bool = False,
+                  keep_order: bool = False) -> torch.Tensor:
     """Shuffle (backward=False: this rank's b local rows -> the b rows its key encoder takes) or un-shuffle
     (backward=True: the encoder's b outputs -> this rank's own rows in their original order).  `take(x, idx)` is the
-    local row gather (ops.gather_rows on the GPU; plain indexing in the CPU tests)."""
+    local row gather (ops.gather_rows on the GPU; plain indexing in the CPU tests).
+    presorted (forward): x is already x[send_rows] (the composition kernel wrote its rows in send order).
+    keep_order (backward): return the received rows as they arrive; the caller reads row back_place[i] for sample i
+    (the loss section's row index) instead of paying a gather."""
     send_rows, place, back_rows, back_place = plan.device_tables(x.device)
     if not backward:
-        recv = _all_to_all_rows(take(x, send_rows), plan.b, plan.recv_counts, plan.send_counts)
+        recv = _all_to_all_rows(x if presorted else take(x, send_rows), plan.b, plan.recv_counts, plan.send_counts)
         return take(recv, place)
     recv = _all_to_all_rows(take(x, back_rows), plan.b, plan.send_counts, plan.recv_counts)
-    return take(recv, back_place)
+    return recv if keep_order else take(recv, back_place)

@@ -2,9 +2,11 @@
 
 `cp2_loss_section` is everything reference `MODEL.forward_cp2` computes between the
 two encoder calls and the returned loss (builder.py:1261-1268, 1279-1292, 1392-1448)
-as nine kernel launches with no host synchronisation.  The gradient with respect to
-the query feature map is produced inside the forward pass (the queue and the P x P
-logits are each visited once more at most), so `backward` is a single scale.
+as ten kernel launches with no host synchronisation (normalise + pool both maps, pool
+finalize, rows-vs-queue + finalize, dense forward + per-sample fold, dense backward, feature
+backward, the three quartile sets, every returned / logged scalar).  The gradient with respect
+to the query feature map is produced inside the forward pass (the queue and the P x P logits are
+each visited once more at most), so `backward` is a single scale.
 """
 from __future__ import annotations
 
@@ -37,20 +39,25 @@ class CP2LossOutputs:
     dense_neg_quartiles: Optional[torch.Tensor] = None    # ... negative pairs
     instance_neg_quartiles: Optional[torch.Tensor] = None # builder.py:1401-1406
     instance_neg_mean: Optional[torch.Tensor] = None      # [B] builder.py:1400
+    scalars: Optional[torch.Tensor] = None                # [24] every returned / logged scalar (cp2_step_scalars layout, S_* indices)
+
+
+# positions in the cp2_step_scalars vector (include/cp2hip.h)
+S_LOSS, S_LOSS_INS, S_LOSS_DENSE, S_ACC1, S_ACC5, S_ACC_DENSE, S_POS_SCORE, S_NEG_SCORE, S_INS_POS = range(9)
+S_VAR_SRC, S_VAR_TGT, S_DPOS_Q, S_DNEG_Q, S_INS_Q, S_INS_NEG_MEAN = 9, 10, 11, 14, 17, 20
 
 
 class _CP2LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q_feat, k_feat, mask_a, mask_b, queue, cfg):
-        (temp_global, temp_local, lmbd_dense, include_background, ids, weights, want_lneg, want_quart, negative) = cfg
+        (temp_global, temp_local, lmbd_dense, include_background, ids, weights, want_lneg, want_quart, negative, k_row) = cfg
         want_lneg = want_lneg or want_quart
         B = q_feat.shape[0]
         need_grad = q_feat.requires_grad
-        q_dense, q_inv, q_part = ops.feat_normalize_pool(q_feat, mask_a)
-        k_dense, _, k_part = ops.feat_normalize_pool(k_feat, mask_b)
+        # query and key map in one launch; the key side through the un-shuffle index when the caller passes one
+        q_dense, k_dense, q_inv, q_part, k_part = ops.feat_normalize_pool_pair(q_feat, k_feat, mask_a, mask_b, k_row)
         P = q_dense.shape[2]
         q_pos, q_neg, q_norms, k_pos, k_neg, extras = ops.pool_finalize(q_part, k_part, P)
-        ne = 3 if include_background else 1
         ext = extras if include_background else extras[:, :1].contiguous()
         C = q_pos.shape[1]
         ins = ops.rowkey_infonce(q_pos, (1, C, 0, 1), B, queue, ext, temp_global,
@@ -64,37 +71,39 @@ class _CP2LossFn(torch.autograd.Function):
             neg = (nscale, None)
         elif ntype in (NEG_AVERAGE, NEG_MEDIAN):
             pre = ops.dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temp_local, ids, weights,
-                                        want_logits=(ntype == NEG_MEDIAN))
+                                        want_logits=(ntype == NEG_MEDIAN), want_batch=False)
             if ntype == NEG_AVERAGE:
                 centre = pre.sample_scal[:, 4].contiguous()
             else:
                 centre = ops.masked_quantiles(pre.logits, P * P, 1, B, P * P, mask_a=mask_a, mask_b=mask_b, want=0)[1].contiguous()
             neg = (nscale, centre)
         den = ops.dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temp_local, ids, weights, want_logits=want_quart,
-                                    negative=neg)
-        loss = ins.loss + den.loss * lmbd_dense
+                                    negative=neg, want_batch=False)
         if need_grad:
-            g_dense = ops.dense_infonce_bwd(q_dense, k_dense, mask_a, mask_b, temp_local, den, lmbd_dense / B, ids, weights,
-                                            negative=neg)
-            if ne == 1:
-                dE = torch.zeros((B, 3), dtype=torch.float32, device=q_feat.device)
-                dE[:, :1] = ins.dE
-            else:
-                dE = ins.dE
-            ds_pos, ds_neg = ops.pool_bwd(ins.drows, dE, q_pos, q_neg, k_pos, k_neg, q_norms, include_background)
-            dq = ops.feat_bwd(q_dense, q_inv, mask_a, g_dense, ds_pos, ds_neg, q_feat)
+            # the dense kernel's split gradients stay un-summed: feat_bwd_fused adds them, and computes the pooled-vector
+            # backward per workgroup (round 2: dense_grad_sum + pool_bwd + two fill kernels for dE)
+            g_part, S = ops.dense_infonce_bwd(q_dense, k_dense, mask_a, mask_b, temp_local, den, lmbd_dense / B, ids, weights,
+                                              negative=neg, keep_partials=True)
+            dq = ops.feat_bwd_fused(q_dense, q_inv, mask_a, g_part, S, ins.drows, ins.dE, q_pos, q_neg, k_pos, k_neg, q_norms,
+                                    include_background, q_feat)
             ctx.save_for_backward(dq)
-        acc1 = (ins.cnt_gt < 1).float().mean() * 100.0
-        acc5 = (ins.cnt_gt < 5).float().mean() * 100.0
-        outs = (loss, ins.loss, den.loss, den.acc, acc1, acc5, k_pos, q_pos, den.sample_scal, extras[:, 0].contiguous())
-        if want_lneg:
-            outs = outs + (ins.lneg,)
+        qs = (None, None, None)
+        lneg_mean = None
         if want_quart:
             K = queue.shape[1]
             dense = dict(x=den.logits, stride_row=P * P, stride_elem=1, R=B, N=P * P, mask_a=mask_a, mask_b=mask_b)
+            row_form = K <= ops.QUANTILES_ROW_MAX and P * P <= ops.QUANTILES_ROW_MAX
+            lneg_mean = torch.empty(B, dtype=torch.float32, device=q_feat.device) if row_form else ins.lneg.mean(1)
             qs = ops.masked_quantiles_multi([dict(dense, want=1), dict(dense, want=0),       # one launch for all three
-                                             dict(x=ins.lneg, stride_row=K, stride_elem=1, R=B, N=K)])
-            outs = outs + (qs[0], qs[1], qs[2], ins.lneg.mean(1))
+                                             dict(x=ins.lneg, stride_row=K, stride_elem=1, R=B, N=K,
+                                                  mean_out=lneg_mean if row_form else None)])
+        # every scalar the step returns or logs: one launch (the loss combination included)
+        scal = ops.step_scalars(ins.loss, ins.cnt_gt, ext, den.sample_scal, q_pos, k_pos, lmbd_dense, qs[0], qs[1], qs[2], lneg_mean)
+        outs = (scal[S_LOSS], scal, k_pos, q_pos, den.sample_scal, extras[:, 0])
+        if want_lneg:
+            outs = outs + (ins.lneg,)
+        if want_quart:
+            outs = outs + (qs[0], qs[1], qs[2], lneg_mean)
         ctx.mark_non_differentiable(*outs[1:])
         return outs
 
@@ -108,9 +117,11 @@ def cp2_loss_section(q_feat: torch.Tensor, k_feat: torch.Tensor, mask_a: torch.T
                      queue: torch.Tensor, *, temp_global: float = 0.2, temp_local: float = 1.0,
                      lmbd_dense: float = 0.2, include_background: bool = False, ids=None,
                      weights: Tuple[float, float, float] = (1.0, 1.0, 1.0), want_lneg: bool = False,
-                     want_quartiles: bool = False, negative_type: int = 0, negative_scale: float = 2.0) -> CP2LossOutputs:
-    """q_feat / k_feat: encoder outputs [B,128,h,w] (NCHW or channels-last, fp32; k already
-    un-shuffled, no grad); mask_a / mask_b: [B,P] down-sampled foreground masks; queue [128,K].
+                     want_quartiles: bool = False, negative_type: int = 0, negative_scale: float = 2.0,
+                     k_row: Optional[torch.Tensor] = None) -> CP2LossOutputs:
+    """q_feat / k_feat: encoder outputs [B,128,h,w] (NCHW or channels-last, fp32; no grad into k); mask_a / mask_b: [B,P]
+    down-sampled foreground masks; queue [128,K].  k_row (int64 [B], optional): sample n's key features are row k_row[n]
+    of k_feat -- the un-shuffle of builder.py:649 without a gather launch; None: k_feat is already in sample order.
     ids = (pixel_ids_a, pixel_ids_b, region_ids_a, region_ids_b) int64 [B,P] when the
     correspondence weights are not all one (reference builder.py:1225-1243)."""
     if ids is not None and tuple(float(w) for w in weights) == (1.0, 1.0, 1.0):
@@ -118,10 +129,14 @@ def cp2_loss_section(q_feat: torch.Tensor, k_feat: torch.Tensor, mask_a: torch.T
     if int(negative_type) not in (NEG_NONE, NEG_FIXED, NEG_AVERAGE, NEG_MEDIAN, NEG_HARD):
         raise ValueError(f"negative_type {negative_type!r}")
     cfg = (float(temp_global), float(temp_local), float(lmbd_dense), bool(include_background), ids,
-           tuple(float(w) for w in weights), bool(want_lneg), bool(want_quartiles), (int(negative_type), float(negative_scale)))
+           tuple(float(w) for w in weights), bool(want_lneg), bool(want_quartiles), (int(negative_type), float(negative_scale)),
+           k_row)
     outs = _CP2LossFn.apply(q_feat, k_feat.detach(), mask_a, mask_b, queue, cfg)
-    res = CP2LossOutputs(*outs[:10])
-    i = 10
+    loss, scal, k_pos, q_pos, sample, ins_pos = outs[:6]
+    res = CP2LossOutputs(loss=loss, loss_instance=scal[S_LOSS_INS], loss_dense=scal[S_LOSS_DENSE], acc_dense=scal[S_ACC_DENSE],
+                         acc1=scal[S_ACC1], acc5=scal[S_ACC5], k_pos=k_pos, q_pos=q_pos, dense_sample=sample, instance_pos=ins_pos,
+                         scalars=scal)
+    i = 6
     if want_lneg or want_quartiles:
         res.lneg = outs[i]
         i += 1

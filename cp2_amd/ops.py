@@ -79,6 +79,33 @@ def compose_mask(img: torch.Tensor, bg: torch.Tensor, stride: int = 0, want_full
     return out, mfull, mds
 
 
+def compose_pair(img_a, bg0, img_b, bg1, stride: int, row_b: Optional[torch.Tensor] = None, channels_last: bool = False,
+                 out_dtype: torch.dtype = torch.float32):
+    """Both views of the step in one launch (reference builder.py:1146-1159): returns (out_a, out_b, mask_ds_a, mask_ds_b).
+    row_b (int64 [B] on the GPU): out_b[j] = compose(img_b[row_b[j]], bg1[row_b[j]]) -- the shuffle-BN gather of
+    builder.py:630 folded in; mask_ds_b stays in the original order.  channels_last / out_dtype=torch.bfloat16: the layout
+    and the precision the stem convolution reads (bf16 = round-to-nearest-even of the fp32 value, as autocast's cast)."""
+    lib = _lib.load()
+    B, ch, H, W = img_a.shape
+    if ch != 3 or any(tuple(t.shape) != (B, 3, H, W) for t in (bg0, img_b, bg1)):
+        raise ValueError("compose_pair: four [B,3,H,W] tensors expected")
+    if out_dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("compose_pair: out_dtype float32 or bfloat16")
+    fmt = torch.channels_last if channels_last else torch.contiguous_format
+    out_a = torch.empty((B, 3, H, W), dtype=out_dtype, device=img_a.device, memory_format=fmt)
+    out_b = torch.empty((B, 3, H, W), dtype=out_dtype, device=img_a.device, memory_format=fmt)
+    md_a = torch.empty((B, ds_size(H, stride), ds_size(W, stride)), dtype=torch.float32, device=img_a.device)
+    md_b = torch.empty_like(md_a)
+    if row_b is not None and (row_b.numel() != B or row_b.dtype != torch.int64):
+        raise ValueError("compose_pair: row_b must hold B int64 indices")
+    rc = lib.cp2_compose_pair(_dev(img_a, "img_a", torch.float32), _dev(bg0, "bg0", torch.float32), _dev(img_b, "img_b", torch.float32),
+                              _dev(bg1, "bg1", torch.float32), out_a.data_ptr(), out_b.data_ptr(), md_a.data_ptr(), md_b.data_ptr(),
+                              _opt(row_b, "row_b", torch.int64), B, H, W, stride, int(channels_last),
+                              int(out_dtype == torch.bfloat16), _stream())
+    _lib.check(rc, "cp2_compose_pair")
+    return out_a, out_b, md_a, md_b
+
+
 def strided_gather(x: torch.Tensor, stride: int) -> torch.Tensor:
     """x[:, s//2::s, s//2::s] for [B,H,W] float32 / int64 (reference builder.py:1155-1186)."""
     lib = _lib.load()
@@ -216,6 +243,25 @@ def corr_iou(ids_a: torch.Tensor, ids_b: torch.Tensor, mask_a: Optional[torch.Te
     return iou, ioum
 
 
+def corr_iou_strided(ids_a: torch.Tensor, ids_b: torch.Tensor, stride: int, mask_a: Optional[torch.Tensor] = None,
+                     mask_b: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """corr_iou of the centre-tap down-sampled id maps (builder.py:1155-1186 + tools/correlation_mapping.py:103-138)
+    without materialising them: ids are the full-resolution int64 [B,H,W] maps, masks the down-sampled [B,P] ones."""
+    lib = _lib.load()
+    B, H, W = ids_a.shape
+    P = ds_size(H, stride) * ds_size(W, stride)
+    iou = torch.empty(B, dtype=torch.float32, device=ids_a.device)
+    ioum = torch.empty(B, dtype=torch.float32, device=ids_a.device) if mask_a is not None else None
+    ma = mask_a.reshape(B, -1) if mask_a is not None else None
+    mb = mask_b.reshape(B, -1) if mask_b is not None else None
+    if ma is not None and (ma.shape[1] != P or mb.shape[1] != P):
+        raise ValueError(f"corr_iou_strided: masks must have {P} elements per sample")
+    rc = lib.cp2_corr_iou_strided(_dev(ids_a, "ids_a", torch.int64), _dev(ids_b, "ids_b", torch.int64), _opt(ma, "mask_a", torch.float32),
+                                  _opt(mb, "mask_b", torch.float32), iou.data_ptr(), _opt(ioum, "iou_masked"), B, H, W, stride, _stream())
+    _lib.check(rc, "cp2_corr_iou_strided")
+    return iou, ioum
+
+
 # ---------------------------------------------------------------- a11
 def ema_scalars(m: float) -> Tuple[float, float]:
     """fp32(m) and fp32(1.0 - m) -- the subtraction is done in double first, as the
@@ -344,12 +390,17 @@ class EmaMultiPlan:
 _ENQUEUE_TICKETS = {}
 
 
-def _enqueue_ticket(device) -> torch.Tensor:
-    """One zeroed int32 per device: the ticket counter of cp2_enqueue (the kernel leaves it zero)."""
-    key = str(device)
-    if key not in _ENQUEUE_TICKETS:
-        _ENQUEUE_TICKETS[key] = torch.zeros(1, dtype=torch.int32, device=device)
-    return _ENQUEUE_TICKETS[key]
+def _enqueue_ticket(queue: torch.Tensor) -> torch.Tensor:
+    """One zeroed int32 per queue buffer: the ticket counter of cp2_enqueue (the kernel leaves it zero).  Keyed by the
+    queue's storage, so `queue` and `queue2`, or enqueues issued on different streams for different queues, never share
+    a counter; a launch that failed re-zeroes its counter (enqueue())."""
+    key = (queue.device.index, queue.data_ptr())
+    t = _ENQUEUE_TICKETS.get(key)
+    if t is None:
+        if len(_ENQUEUE_TICKETS) >= 64:                   # queues come and go in tests: drop the oldest entry
+            _ENQUEUE_TICKETS.pop(next(iter(_ENQUEUE_TICKETS)))
+        t = _ENQUEUE_TICKETS[key] = torch.zeros(1, dtype=torch.int32, device=queue.device)
+    return t
 
 
 def enqueue(queue: torch.Tensor, keys: torch.Tensor, ptr: torch.Tensor) -> None:
@@ -362,8 +413,11 @@ def enqueue(queue: torch.Tensor, keys: torch.Tensor, ptr: torch.Tensor) -> None:
         raise ValueError(f"enqueue: keys have {c2} channels, queue has {C}")
     if ptr.numel() != 1:
         raise ValueError("enqueue: ptr must hold one int64")
+    ticket = _enqueue_ticket(queue)
     rc = lib.cp2_enqueue(_dev(queue, "queue", torch.float32), _dev(keys, "keys", torch.float32),
-                         _dev(ptr, "queue_ptr", torch.int64), _enqueue_ticket(queue.device).data_ptr(), n, C, K, _stream())
+                         _dev(ptr, "queue_ptr", torch.int64), ticket.data_ptr(), n, C, K, _stream())
+    if rc:
+        ticket.zero_()                                    # re-establish the "kernels leave it zero" invariant
     _lib.check(rc, "cp2_enqueue")
 
 
@@ -434,6 +488,69 @@ def feat_bwd(dense, inv_norm, mask, g_dense, ds_pos, ds_neg, like: torch.Tensor)
                           _dev(ds_pos, "ds_pos"), _dev(ds_neg, "ds_neg"), dfeat.data_ptr(), sn, sc, sp, B, C, P, _stream())
     _lib.check(rc, "cp2_feat_bwd")
     return dfeat
+
+
+def feat_normalize_pool_pair(q_feat: torch.Tensor, k_feat: torch.Tensor, mask_a: torch.Tensor, mask_b: torch.Tensor,
+                             k_row: Optional[torch.Tensor] = None):
+    """feat_normalize_pool of the query and the key map in one launch; sample n of the key side is read from row
+    k_row[n] of k_feat (the un-shuffle index, builder.py:649).  Returns (q_dense, k_dense, q_inv_norm, q_partial, k_partial)."""
+    lib = _lib.load()
+    for t, name in ((q_feat, "q_feat"), (k_feat, "k_feat")):
+        if not t.is_cuda:
+            raise _lib.Cp2LibraryError(f"{name} is on {t.device}; cp2_amd ops run on the GPU only")
+        if t.dtype != torch.float32:
+            raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    B, C, P, qsn, qsc, qsp = _feat_strides(q_feat)
+    B2, C2, P2, ksn, ksc, ksp = _feat_strides(k_feat)
+    if (B2, C2, P2) != (B, C, P):
+        raise ValueError("feat_normalize_pool_pair: query and key maps differ in shape")
+    dev = q_feat.device
+    q_dense = torch.empty((B, C, P), dtype=torch.float32, device=dev)
+    k_dense = torch.empty((B, C, P), dtype=torch.float32, device=dev)
+    inv = torch.empty((B, P), dtype=torch.float32, device=dev)
+    NT = (P + 63) // 64
+    q_part = torch.empty((B, NT, 2, C), dtype=torch.float32, device=dev)
+    k_part = torch.empty((B, NT, 2, C), dtype=torch.float32, device=dev)
+    rc = lib.cp2_feat_normalize_pool_pair(q_feat.data_ptr(), qsn, qsc, qsp, k_feat.data_ptr(), ksn, ksc, ksp,
+                                          _opt(k_row, "k_row", torch.int64), _dev(mask_a, "mask_a", torch.float32),
+                                          _dev(mask_b, "mask_b", torch.float32), q_dense.data_ptr(), k_dense.data_ptr(),
+                                          inv.data_ptr(), q_part.data_ptr(), k_part.data_ptr(), B, C, P, _stream())
+    _lib.check(rc, "cp2_feat_normalize_pool_pair")
+    return q_dense, k_dense, inv, q_part, k_part
+
+
+def feat_bwd_fused(dense, inv_norm, mask, g_part: torch.Tensor, S: int, drow_pos, dE, q_pos, q_neg, k_pos, k_neg, q_norms,
+                   include_background: bool, like: torch.Tensor) -> torch.Tensor:
+    """feat_bwd with the sum of the dense kernel's S split gradients (g_part: [S,B,C,P], or [B,C,P] with S = 1) and the
+    pooled-vector backward (pool_bwd) folded in; dE: [B,NE]."""
+    lib = _lib.load()
+    dfeat = torch.empty_like(like)
+    B, C, P, sn, sc, sp = _feat_strides(dfeat)
+    rc = lib.cp2_feat_bwd_fused(_dev(dense, "dense"), _dev(inv_norm, "inv_norm"), _dev(mask, "mask"), _dev(g_part, "g_part", torch.float32),
+                                int(S), B * C * P, _dev(drow_pos, "drow_pos"), _dev(dE, "dE"), dE.shape[1], _dev(q_pos, "q_pos"),
+                                _dev(q_neg, "q_neg"), _dev(k_pos, "k_pos"), _dev(k_neg, "k_neg"), _dev(q_norms, "q_norms"),
+                                int(include_background), dfeat.data_ptr(), sn, sc, sp, B, C, P, _stream())
+    _lib.check(rc, "cp2_feat_bwd_fused")
+    return dfeat
+
+
+STEP_SCALARS = 24          # CP2_STEP_SCALARS
+
+
+def step_scalars(ins_loss, cnt_gt, extras, sample_scal, q_pos, k_pos, lmbd_dense: float, dense_pos_q=None, dense_neg_q=None,
+                 ins_neg_q=None, lneg_mean=None) -> torch.Tensor:
+    """Every scalar the step returns or logs in one launch -> float32 [24] (layout: include/cp2hip.h cp2_step_scalars)."""
+    lib = _lib.load()
+    B, C = q_pos.shape
+    out = torch.empty(STEP_SCALARS, dtype=torch.float32, device=q_pos.device)
+    rc = lib.cp2_step_scalars(_dev(ins_loss, "ins_loss", torch.float32), _dev(cnt_gt, "cnt_gt", torch.int32),
+                              _dev(extras, "extras", torch.float32), extras.shape[1], _dev(sample_scal, "sample_scal", torch.float32),
+                              _dev(q_pos, "q_pos", torch.float32), _dev(k_pos, "k_pos", torch.float32),
+                              _opt(dense_pos_q, "dense_pos_q", torch.float32), _opt(dense_neg_q, "dense_neg_q", torch.float32),
+                              _opt(ins_neg_q, "ins_neg_q", torch.float32), _opt(lneg_mean, "lneg_mean", torch.float32),
+                              float(lmbd_dense), out.data_ptr(), B, C, _stream())
+    _lib.check(rc, "cp2_step_scalars")
+    return out
 
 
 # ---------------------------------------------------------------- a10 / a16
@@ -531,7 +648,8 @@ def _negative(negative):
 
 
 def dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temperature: float, ids=None,
-                      weights=(1.0, 1.0, 1.0), want_logits: bool = False, split: bool = True, negative=None) -> DenseResult:
+                      weights=(1.0, 1.0, 1.0), want_logits: bool = False, split: bool = True, negative=None,
+                      want_batch: bool = True) -> DenseResult:
     lib = _lib.load()
     nmode, nscale, ncen = _negative(negative)
     B, C, P = q_dense.shape
@@ -541,7 +659,7 @@ def dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temperature: float, ids=
     res.lse, colsum, possum, allsum, res.colmax = f(), f(), f(), f(), f()
     res.argx = torch.empty((B, P), dtype=torch.int32, device=dev)
     res.sample_scal = torch.empty((B, 8), dtype=torch.float32, device=dev)
-    batch = torch.empty(2, dtype=torch.float32, device=dev)
+    batch = torch.empty(2, dtype=torch.float32, device=dev) if want_batch else None    # None: cp2_step_scalars forms the means
     res.logits = torch.empty((B, P, P), dtype=torch.float32, device=dev) if want_logits else None
     pa, pb, ra, rb = _ids4(ids)
     S = lib.cp2_dense_num_splits(B, P) if split else 1
@@ -552,29 +670,33 @@ def dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temperature: float, ids=
                                    pa, pb, ra, rb, float(weights[0]), float(weights[1]), float(weights[2]),
                                    float(temperature), res.lse.data_ptr(), colsum.data_ptr(), possum.data_ptr(),
                                    allsum.data_ptr(), res.colmax.data_ptr(), res.argx.data_ptr(),
-                                   res.sample_scal.data_ptr(), batch.data_ptr(), _opt(res.logits, "logits"),
+                                   res.sample_scal.data_ptr(), _opt(batch, "batch"), _opt(res.logits, "logits"),
                                    split_ws.data_ptr() if split_ws is not None else None, nmode, nscale, ncen, B, C, P, _stream())
     _lib.check(rc, "cp2_dense_infonce_fwd")
-    res.loss, res.acc = batch[0], batch[1]
+    res.loss, res.acc = (batch[0], batch[1]) if want_batch else (None, None)
     return res
 
 
 def dense_infonce_bwd(q_dense, k_dense, mask_a, mask_b, temperature: float, fwd: DenseResult, grad_scale: float,
-                      ids=None, weights=(1.0, 1.0, 1.0), split: bool = True, negative=None) -> torch.Tensor:
+                      ids=None, weights=(1.0, 1.0, 1.0), split: bool = True, negative=None, keep_partials: bool = False):
+    """d loss / d q_dense.  keep_partials: return (g_part, S) -- the S split gradients [S,B,C,P] un-summed (feat_bwd_fused
+    adds them), or the gradient itself with S = 1 when the shape needs no split."""
     lib = _lib.load()
     nmode, nscale, ncen = _negative(negative)
     B, C, P = q_dense.shape
-    g = torch.empty_like(q_dense)
     pa, pb, ra, rb = _ids4(ids)
     S = lib.cp2_dense_num_splits(B, P) if split else 1
-    split_ws = torch.empty(S * B * C * P, dtype=torch.float32, device=q_dense.device) if S > 1 else None
+    split_ws = torch.empty((S, B, C, P), dtype=torch.float32, device=q_dense.device) if S > 1 else None
+    g = None if (keep_partials and S > 1) else torch.empty_like(q_dense)
     _profile("dense_bwd")
     rc = lib.cp2_dense_infonce_bwd(_dev(q_dense, "q_dense"), _dev(k_dense, "k_dense"), _dev(mask_a, "mask_a"),
                                    _dev(mask_b, "mask_b"), pa, pb, ra, rb, float(weights[0]), float(weights[1]),
                                    float(weights[2]), float(temperature), fwd.lse.data_ptr(), fwd.sample_scal.data_ptr(),
-                                   float(grad_scale), g.data_ptr(), split_ws.data_ptr() if split_ws is not None else None,
+                                   float(grad_scale), _opt(g, "g_dense"), split_ws.data_ptr() if split_ws is not None else None,
                                    nmode, nscale, ncen, B, C, P, _stream())
     _lib.check(rc, "cp2_dense_infonce_bwd")
+    if keep_partials:
+        return (split_ws, S) if S > 1 else (g, 1)
     return g
 
 
@@ -605,9 +727,12 @@ def _quant_workspace(dev, R, N, NQ):
         nbytes = _lib.load().cp2_quantiles_workspace_bytes(n, I32(*R), I32(*N), NQ)
         if nbytes <= 0:
             raise ValueError("masked_quantiles: bad job shapes")
-        if len(_QUANT_WS) >= 16:                      # tests sweep many shapes: do not hoard
-            _QUANT_WS.clear()
-        ws = _QUANT_WS[key] = torch.zeros(nbytes // 4, dtype=torch.int32, device=dev)
+        if len(_QUANT_WS) >= 16:                      # tests sweep many shapes: drop the least recently used ONE (the
+            _QUANT_WS.pop(next(iter(_QUANT_WS)))      # others may be in flight on a stream; the allocator keeps a freed block
+        ws = torch.zeros(nbytes // 4, dtype=torch.int32, device=dev)   # alive until queued work on its stream has run)
+    else:
+        del _QUANT_WS[key]
+    _QUANT_WS[key] = ws                               # re-insert: dict order = recency
     return ws
 
 
@@ -630,6 +755,8 @@ def masked_quantiles_multi(jobs, q: Optional[torch.Tensor] = None):
     if q is None:
         q = _quartile_tensor(dev)
     outs = [torch.empty((q.numel(), j["R"]), dtype=torch.float32, device=dev) for j in jobs]
+    # job key "mean_out": a float32 [R] tensor that receives the row means (one-launch form, unmasked jobs only)
+    means = [_opt(j.get("mean_out"), "mean_out", torch.float32) for j in jobs]
     P_ = ctypes.c_void_p * n
     I64, I32 = ctypes.c_int64 * n, ctypes.c_int * n
     for j in jobs:
@@ -646,7 +773,10 @@ def masked_quantiles_multi(jobs, q: Optional[torch.Tensor] = None):
         I32(*[j["R"] for j in jobs]), I32(*[j["N"] for j in jobs]), P_(*ma), P_(*mb),
         I32(*[(j["mask_a"].shape[1] if j.get("mask_a") is not None else 0) for j in jobs]),
         I32(*[j.get("want", -1) for j in jobs]), _dev(q, "q", torch.float32), q.numel(), P_(*[o.data_ptr() for o in outs]),
+        P_(*means) if any(m is not None for m in means) else None,
         None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel() * 4, _stream())
+    if rc and ws is not None:
+        ws.zero_()                                        # a failed call may have left counts behind
     _lib.check(rc, "cp2_masked_quantiles_multi")
     return outs
 

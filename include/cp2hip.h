@@ -52,6 +52,15 @@ int cp2_profile_next_launch(void* start_event, void* stop_event);
 int cp2_compose_mask(const float* img, const float* bg, float* out_img, float* mask_full,
                      float* mask_ds, int B, int H, int W, int stride, void* stream);
 
+/* Both views in one launch (the training step's form), with three later launches folded in: the key view's rows may
+ * be written in shuffle-BN order (row_b: device int64 [B] or NULL; out_b[j] = compose(img_b[row_b[j]], bg1[row_b[j]]),
+ * builder.py:609-630 -- mask_ds_b stays in the original row order), and the output may be channels-last and / or bf16
+ * (round-to-nearest-even of the fp32 value; what autocast's cast in front of the stem convolution produces).
+ * W % 4 == 0, 16-byte aligned pointers.  out_a / out_b: [B,3,H,W] logical, fp32 or bf16 (out_bf16), NCHW or NHWC memory. */
+int cp2_compose_pair(const float* img_a, const float* bg0, const float* img_b, const float* bg1, void* out_a, void* out_b,
+                     float* mask_ds_a, float* mask_ds_b, const int64_t* row_b, int B, int H, int W, int stride,
+                     int channels_last, int out_bf16, void* stream);
+
 /* ---- a2: centre-tap strided down-sample ---------------- builder.py:1155-1186, loader.py:39-43
  * y[b,i,j] = x[b, s/2 + s*i, s/2 + s*j];  x: [B,H,W], y: [B,Hs,Ws]. */
 int cp2_strided_gather_f32(const float* x, float* y, int B, int H, int W, int stride, void* stream);
@@ -71,6 +80,10 @@ int cp2_gather_rows_f32(const float* src, const int64_t* idx, float* dst, int ro
  * ids: [B,P] int64; masks: [B,P] f32 (may be NULL when iou_masked is NULL).  P <= 16383. */
 int cp2_corr_iou(const int64_t* ids_a, const int64_t* ids_b, const float* mask_a, const float* mask_b,
                  float* iou, float* iou_masked, int B, int P, void* stream);
+/* Same, with the centre-tap down-sampling (a2) of the id maps folded in: ids are the full-resolution [B,H,W] maps, read
+ * at (s/2 + s*i, s/2 + s*j); masks are already down-sampled, [B, Hs*Ws]. */
+int cp2_corr_iou_strided(const int64_t* ids_a, const int64_t* ids_b, const float* mask_a, const float* mask_b,
+                         float* iou, float* iou_masked, int B, int H, int W, int stride, void* stream);
 
 /* ---- a11: momentum (EMA) update of the key encoder -------- builder.py:557-567
  * k[i] = k[i]*m + q[i]*one_minus_m  (two rounded products, one rounded sum; no FMA).
@@ -121,6 +134,36 @@ int cp2_feat_bwd(const float* dense, const float* inv_norm, const float* mask, c
                  const float* ds_pos, const float* ds_neg, float* dfeat, int64_t stride_n, int64_t stride_c,
                  int64_t stride_p, int B, int C, int P, void* stream);
 
+/* The training step's forms of a7 (round 3).
+ * cp2_feat_normalize_pool_pair: query AND key map in one launch (the two cp2_feat_normalize_pool calls of a step); the
+ * key side reads sample n from row k_row[n] of the key encoder's output (k_row: device int64 [B] or NULL) -- the
+ * un-shuffle gather of builder.py:649 folded in.  Channels-last maps are staged through LDS (16-byte coalesced reads).
+ * cp2_feat_bwd_fused: cp2_feat_bwd with two launches folded in -- the dense gradient is the sum over s < S of
+ * g_part[s * split_stride + ...] in that order (what cp2_dense_infonce_bwd leaves in split_ws when g_dense is NULL; S = 1:
+ * g_part is the gradient itself), and d loss / d(pooled sums) is computed per workgroup from cp2_pool_bwd's inputs
+ * (dE: [B,NE], NE = 1 without / 3 with the background logits). */
+int cp2_feat_normalize_pool_pair(const float* q_feat, int64_t q_sn, int64_t q_sc, int64_t q_sp, const float* k_feat,
+                                 int64_t k_sn, int64_t k_sc, int64_t k_sp, const int64_t* k_row, const float* mask_a,
+                                 const float* mask_b, float* q_dense, float* k_dense, float* q_inv_norm, float* q_partial,
+                                 float* k_partial, int B, int C, int P, void* stream);
+int cp2_feat_bwd_fused(const float* dense, const float* inv_norm, const float* mask, const float* g_part, int S,
+                       int64_t split_stride, const float* drow_pos, const float* dE, int NE, const float* q_pos, const float* q_neg,
+                       const float* k_pos, const float* k_neg, const float* q_norms, int include_background, float* dfeat,
+                       int64_t stride_n, int64_t stride_c, int64_t stride_p, int B, int C, int P, void* stream);
+
+/* ---- a15 at batch level + the loss combination: every scalar a CP2 step returns or logs, one launch ------------------
+ * builder.py:1431-1448 (loss, accuracies), :1265,1282 (cross-image spread), :1553-1604 (logged scalars).
+ * out[CP2_STEP_SCALARS]: 0 loss = loss_instance + lmbd_dense * loss_dense, 1 loss_instance, 2 loss_dense, 3 top-1 %,
+ * 4 top-5 %, 5 dense arg-max accuracy %, 6 / 7 mean positive / negative dense score, 8 mean raw positive instance logit,
+ * 9 / 10 mean over channels of the unbiased batch std of q_pos / k_pos, 11-13 / 14-16 / 17-19 batch means of the
+ * [3,B] quartile sets (positive dense, negative dense, queue logits; NULL -> 0), 20 batch mean of lneg_mean (NULL -> 0).
+ * ins_loss: device scalar; cnt_gt: int32 [B]; extras: [B,NE] (column 0 = raw positive logit); sample_scal: [B,8]. */
+#define CP2_STEP_SCALARS 24
+int cp2_step_scalars(const float* ins_loss, const int32_t* cnt_gt, const float* extras, int NE, const float* sample_scal,
+                     const float* q_pos, const float* k_pos, const float* dense_pos_quart, const float* dense_neg_quart,
+                     const float* ins_neg_quart, const float* lneg_mean, float lmbd_dense, float* out, int B, int C,
+                     void* stream);
+
 /* ---- a10 / a16: rows-vs-queue InfoNCE (f32 MFMA) ---------- builder.py:1395-1428 (instance),
  *                                                            :866-873,906-908,150-176 (DenseCL local)
  * logits of row r = [extras[r,:NE] | rows[r].keys[:,j], j<K] / T, target = extras column 0;
@@ -159,11 +202,12 @@ int cp2_rowkey_infonce_finalize(const float* part_m, const float* part_s, const 
  * (pixel match -> w_pixel, else known-region match -> w_region, else w_not); NULL = all weights 1.
  * Per key pixel outputs [B,P]: lse, colsum_a, possum, allsum, colmax, argx (workspaces kept for backward /
  * logging).  sample_scal [B,8] = {Sa, Sb, loss_n, mean positive score, mean negative score, label at the
- * arg-max pair, 0, 0};  batch_out[2] = {mean_n loss_n, 100 * mean_n label}.
+ * arg-max pair, 0, 0};  batch_out[2] = {mean_n loss_n, 100 * mean_n label}, or NULL when the caller forms the batch
+ * means itself (cp2_step_scalars).
  * logits_out: NULL, or [B,P,P] to also receive the raw logits q.k (only for the logging quantiles).   C = 128.
  * split_ws: NULL (one workgroup per (sample, 128-key tile) walks all query pixels), or float[7 * S * B * P] with
  * S = cp2_dense_num_splits(B, P): S workgroups share the walk and a merge kernel folds their partial statistics, so
- * small B*P still fills the chip.
+ * small B*P still fills the chip (the fold and the per-sample scalars are one launch, one workgroup per sample).
  * negative_mode != 0 (reference NegativeType FIXED / AVERAGE / MEDIAN, builder.py:1332-1386): the raw logit L of every
  * NEGATIVE pair (mask_a[x]*mask_b[y] == 0) enters the loss as 2 / (1 + exp(-negative_scale * (L - centre))) - 1 with
  * centre = negative_center[n] (device float[B]: the sample's mean or median negative score, taken from a first
@@ -178,7 +222,8 @@ int cp2_dense_infonce_fwd(const float* q_dense, const float* k_dense, const floa
                           int P, void* stream);
 /* g_dense [B,C,P] = grad_scale * d (sum_n loss_n) / d q_dense, recomputing the logits tile by tile.
  * split_ws: NULL, or float[S * B * C * P] with S = cp2_dense_num_splits(B, P): the key-pixel range is shared by S
- * workgroups and their partial gradients are added in split order (deterministic). */
+ * workgroups and their partial gradients are added in split order (deterministic).  g_dense may be NULL when split_ws
+ * is given and S > 1: the S partial gradients [S][B][C][P] stay in split_ws for cp2_feat_bwd_fused to add. */
 int cp2_dense_infonce_bwd(const float* q_dense, const float* k_dense, const float* mask_a, const float* mask_b,
                           const int64_t* pix_a, const int64_t* pix_b, const int64_t* reg_a, const int64_t* reg_b,
                           float w_pixel, float w_region, float w_not, float temperature, const float* lse,
@@ -200,13 +245,15 @@ int cp2_masked_quantiles(const float* x, int64_t stride_row, int64_t stride_elem
  * When every job has N <= CP2_QUANTILES_ROW_MAX the call is ONE launch (one workgroup per row through all three
  * levels) and needs no workspace (NULL, 0).  Otherwise:
  * workspace: device memory of cp2_quantiles_workspace_bytes(njobs, R, N, NQ) bytes, 16-byte aligned, ZERO before the
- * first call; every call leaves it zero again, so the same buffer serves every later call with the SAME (R, N, NQ). */
+ * first call; every call leaves it zero again, so the same buffer serves every later call with the SAME (R, N, NQ).
+ * mean_out: NULL, or a HOST array of njobs DEVICE pointers (NULL entries allowed): job j's row means [R] as torch's
+ * x.mean(1) (NaN when the row holds a NaN), from the first pass of the one-launch form (want < 0 jobs only). */
 #define CP2_QUANTILES_ROW_MAX 131072
 int64_t cp2_quantiles_workspace_bytes(int njobs, const int* R, const int* N, int NQ);
 int cp2_masked_quantiles_multi(int njobs, const float* const* x, const int64_t* stride_row, const int64_t* stride_elem,
                                const int* R, const int* N, const float* const* mask_a, const float* const* mask_b,
                                const int* P, const int* want, const float* q, int NQ, float* const* out,
-                               void* workspace, int64_t workspace_bytes, void* stream);
+                               float* const* mean_out, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- f1: on-device two-crop augmentation + background erasing --- loader.py:39-43,50-118; main.py:204-225
  * One launch makes B output samples from a dataset resident in device memory: src [N,3,Hs,Ws] fp32 in [0,1]
