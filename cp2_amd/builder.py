@@ -509,7 +509,8 @@ class MODEL(nn.Module):
         _batch_unshuffle_ddp needs to undo it.  shuffle_exchange = "all_to_all" (default): only the rows this rank keeps
         travel (dist.ShufflePlan), the permutation is drawn on every host from a generator seeded once by rank 0;
         "all_gather": the reference's form -- gather everything, broadcast the permutation, keep a slice."""
-        x = x.contiguous()
+        if not (x.is_contiguous() or (x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last))):
+            x = x.contiguous()
         if x.is_cuda:
             x.record_stream(torch.cuda.current_stream())      # may be read here on the side stream after its owner drops it
         w = cdist.world_size()
@@ -518,14 +519,16 @@ class MODEL(nn.Module):
             host = idx_shuffle.cpu() if idx_shuffle is not None else cdist.shared_permutation(n_all, x.device)
             plan = cdist.ShufflePlan(host, cdist.rank(), w)
             with self._comm("c1_image_exchange"):
-                taken = cdist.exchange_rows(x, plan, take=ops.gather_rows)
+                rows, restore = _rows_as_f32(x)
+                taken = restore(cdist.exchange_rows(rows, plan, take=ops.gather_rows))
             return taken, plan
         with self._comm("c1_image_exchange"):
-            x_gather = concat_all_gather(x)
+            rows, restore = _rows_as_f32(x)                  # any dense layout / fp32 or bf16: rows of 4-byte words
+            x_gather = concat_all_gather(rows)
             if idx_shuffle is None:
                 idx_shuffle = cdist.make_shuffle_index(x_gather.shape[0], x.device)
             idx_unshuffle = torch.argsort(idx_shuffle)
-            taken = ops.gather_rows(x_gather, cdist.shuffle_rows_for_rank(idx_shuffle, cdist.rank(), w).contiguous())
+            taken = restore(ops.gather_rows(x_gather, cdist.shuffle_rows_for_rank(idx_shuffle, cdist.rank(), w).contiguous()))
         return taken, idx_unshuffle
 
     @torch.no_grad()

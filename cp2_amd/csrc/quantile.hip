@@ -65,10 +65,13 @@ struct QuantJobs {
     unsigned* hist2;                       // [rows][QMAX][QB1]
     unsigned* above;                       // [rows][QMAX] max over ~key of the elements above the 22-bit prefix (0 = none)
     unsigned* sel;                         // [rows][QSEL]: n | per quantile: prefix so far, rank inside it
+                                           //   (cooperative form: [0] arrivals, [1] departures, [2] time-out flag)
+    double* sums;                          // [rows][QCOOP_CHUNKS] partial row sums (cooperative form, mean_out)
 };
 constexpr int QSEL = 1 + 2 * QMAX;
-// per-row workspace words: hist0 | hist1 | hist2 | above | sel
-constexpr int64_t QROW_WORDS = QB0 + 2 * QMAX * QB1 + QMAX + QSEL;
+constexpr int QCOOP_CHUNKS = 16;           // chunks per row of the one-launch cooperative form (QROW_MAX / QCHUNK)
+// per-row workspace words: hist0 | hist1 | hist2 | above | sel | sums (the cooperative form's per-chunk partial row sums, doubles)
+constexpr int64_t QROW_WORDS = QB0 + 2 * QMAX * QB1 + QMAX + QSEL + 2 * QCOOP_CHUNKS;
 
 template <int NT>
 __device__ __forceinline__ unsigned block_scan_incl(unsigned v, unsigned* wtot) {
@@ -571,12 +574,222 @@ __global__ __launch_bounds__(QT3) void quantiles_row_kernel(QuantJobs jobs) {
 #undef CP2_Q_FOREACH
 }
 
+// ---- rows of at most QROW_MAX elements, a few hundred chunks in total (the training step: 576): ONE launch, one
+// 256-thread workgroup per 8192-element chunk.  The chunk is loaded once and stays in registers through the three levels;
+// after each level the chunks of a row meet at a row-local barrier (an arrival counter in the workspace: every chunk of
+// the call is resident at once -- the host only takes this path below QCOOP_MAX_WGS workgroups, a fraction of the 256 CUs'
+// slots -- so the spin ends; it is bounded anyway and raises a flag in the workspace instead of hanging).  Every chunk
+// re-derives the row's selection from the global histograms itself, so a level costs one barrier, not two; the row's
+// first chunk writes the result and leaves the workspace zero for the next call.
+// Round 2 had one 1024-thread workgroup per row walk its row three times (66 us: ~30 VALU instructions per element on
+// the ONE CU a row had; 96 of 256 CUs busy); here 576 workgroups share the same work.
+constexpr int QCOOP_MAX_WGS = 768;      // 256 CUs x 3 resident workgroups (launch bounds below): every chunk of the call is on the chip at once
+
+__device__ __forceinline__ unsigned ld_agent(const unsigned* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// All chunks of the row have arrived `target` times in total.  Returns false on time-out (flag raised).
+__device__ __forceinline__ bool row_barrier(unsigned* sel, unsigned target) {
+    __shared__ int ok;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();                                   // this chunk's histogram adds are performed before the arrival
+        atomicAdd(&sel[0], 1u);
+        unsigned spins = 0;
+        bool good = true;
+        while (ld_agent(&sel[0]) < target) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1u << 22)) { atomicExch(&sel[2], 1u); good = false; break; }
+        }
+        __threadfence();
+        ok = good;
+    }
+    __syncthreads();
+    return ok != 0;
+}
+
+__global__ __launch_bounds__(QT1, 3) void quantiles_coop_kernel(QuantJobs jobs) {      // 3 workgroups per CU: 768 resident
+    constexpr int BPT0 = QB0 / QT1, BPT1 = QB1 / QT1;
+    __shared__ unsigned h[QMAX * QB1];                      // level 0 uses it as the QB0-bin histogram (QB0 == QMAX * QB1)
+    __shared__ unsigned wtot[QT1 / 64];
+    __shared__ unsigned sh_min[QMAX], sh_bin[QMAX], sh_kk[QMAX], sh_next[QMAX], sh_n;
+    __shared__ double sum_w[QT1 / 64];
+    static_assert(QB0 == QMAX * QB1, "one LDS histogram serves every level");
+    const int jsel = job_of(jobs.first_chunk, (int)blockIdx.x);
+    const QuantArgs& a = jobs.job[jsel];
+    const int c = (int)blockIdx.x - jobs.first_chunk[jsel], r = c / a.chunks, s = c - r * a.chunks;
+    const int tid = threadIdx.x, NQ = a.NQ, G = a.chunks;
+    const int64_t rt = jobs.first_row[jsel] + r;
+    unsigned* sel = jobs.sel + rt * QSEL;
+    unsigned* g0 = jobs.hist0 + rt * QB0;
+    unsigned* g1 = jobs.hist1 + rt * QMAX * QB1;
+    unsigned* g2 = jobs.hist2 + rt * QMAX * QB1;
+    const int begin = s * QCHUNK, end = min(a.N, begin + QCHUNK);
+    ChunkData<QT1> d;
+    chunk_load<QT1>(a, r, begin, end, d);                  // the only read of the data
+    // ---------------------------------------------------------------- level 0: top 12 bits of every kept element
+    for (int i = tid; i < QB0; i += QT1) h[i] = 0;
+    __syncthreads();
+    float lsum = 0.f;
+    chunk_visit<QT1>(a, r, begin, end, d, [&](unsigned k) { atomicAdd(&h[k >> 20], 1u); lsum += key2f(k); });
+    if (a.mean_out) {
+        double ds = (double)lsum;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ds += __shfl_xor(ds, off, 64);
+        if ((tid & 63) == 0) sum_w[tid >> 6] = ds;
+    }
+    __syncthreads();
+    for (int i = tid; i < QB0; i += QT1) {
+        const unsigned v = h[i];
+        if (v) atomicAdd(&g0[i], v);
+    }
+    if (a.mean_out && tid == 0) {
+        double t = 0;
+        for (int i = 0; i < QT1 / 64; ++i) t += sum_w[i];
+        __hip_atomic_store(&jobs.sums[rt * QCOOP_CHUNKS + s], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!row_barrier(sel, (unsigned)G)) return;
+    unsigned n;
+    {   // select 0, by every chunk for itself: rank -> (first-level bin, rank inside it)
+        unsigned hv[BPT0];
+#pragma unroll
+        for (int u = 0; u < BPT0; ++u) hv[u] = ld_agent(&g0[BPT0 * tid + u]);
+        unsigned tot = 0;
+#pragma unroll
+        for (int u = 0; u < BPT0; ++u) tot += hv[u];
+        const unsigned incl = block_scan_incl<QT1>(tot, wtot), excl = incl - tot;
+        if (tid == QT1 - 1) sh_n = incl;
+        __syncthreads();
+        n = sh_n;
+        if (n > 0)
+            for (int j = 0; j < NQ; ++j) locate<BPT0>(hv, excl, incl, (unsigned)floorf(a.q[j] * (float)(n - 1)), &sh_bin[j], &sh_kk[j]);
+        __syncthreads();
+    }
+    unsigned pre[QMAX], kk[QMAX];
+#pragma unroll
+    for (int j = 0; j < QMAX; ++j) { pre[j] = (n > 0 && j < NQ) ? sh_bin[j] : QNONE; kk[j] = (n > 0 && j < NQ) ? sh_kk[j] : 0u; }
+    // ---------------------------------------------------------------- levels 1 and 2: ten more bits each, per quantile
+    unsigned hv2[QMAX][BPT1];
+    for (int level = 1; level <= 2; ++level) {
+        unsigned* g = level == 1 ? g1 : g2;
+        __syncthreads();
+        for (int i = tid; i < QMAX * QB1; i += QT1) h[i] = 0;
+        if (tid < QMAX) sh_min[tid] = QNONE;
+        __syncthreads();
+        if (n > 0) {
+            unsigned mn[QMAX];
+#pragma unroll
+            for (int j = 0; j < QMAX; ++j) mn[j] = QNONE;
+            chunk_visit<QT1>(a, r, begin, end, d, [&](unsigned k) {
+                const unsigned top = level == 1 ? (k >> 20) : (k >> 10);
+                const unsigned bin = level == 1 ? ((k >> 10) & (QB1 - 1)) : (k & (QB1 - 1));
+#pragma unroll
+                for (int j = 0; j < QMAX; ++j) {
+                    if (top == pre[j]) atomicAdd(&h[j * QB1 + bin], 1u);
+                    else if (level == 2 && j < NQ && top > pre[j]) mn[j] = min(mn[j], k);
+                }
+            });
+            if (level == 2) {
+#pragma unroll
+                for (int j = 0; j < QMAX; ++j) {
+                    unsigned m = mn[j];
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, off, 64));
+                    if ((tid & 63) == 0 && m != QNONE) atomicMin(&sh_min[j], m);
+                }
+            }
+            __syncthreads();
+            for (int i = tid; i < NQ * QB1; i += QT1) {
+                const unsigned v = h[i];
+                if (v) atomicAdd(&g[i], v);
+            }
+            if (level == 2 && tid < NQ && sh_min[tid] != QNONE) atomicMax(&jobs.above[rt * QMAX + tid], ~sh_min[tid]);
+        }
+        if (!row_barrier(sel, (unsigned)((level + 1) * G))) return;
+        if (s == 0) {                                      // the previous level's histogram has been read by everyone
+            unsigned* z = level == 1 ? g0 : g1;
+            for (int i = tid; i < QB0; i += QT1) z[i] = 0u;
+        }
+        if (level == 2 && s != 0) break;                   // only the row's first chunk finishes the row
+        if (n == 0) continue;
+#pragma unroll
+        for (int j = 0; j < QMAX; ++j)
+#pragma unroll
+            for (int u = 0; u < BPT1; ++u) hv2[j][u] = j < NQ ? ld_agent(&g[j * QB1 + BPT1 * tid + u]) : 0u;
+        if (tid < QMAX) sh_next[tid] = QNONE;
+#pragma unroll
+        for (int j = 0; j < QMAX; ++j) {
+            if (j < NQ) {
+                unsigned tot = 0;
+#pragma unroll
+                for (int u = 0; u < BPT1; ++u) tot += hv2[j][u];
+                const unsigned incl = block_scan_incl<QT1>(tot, wtot);
+                locate<BPT1>(hv2[j], incl - tot, incl, kk[j], &sh_bin[j], &sh_kk[j]);
+            }
+        }
+        __syncthreads();
+        if (level == 1) {
+#pragma unroll
+            for (int j = 0; j < QMAX; ++j)
+                if (j < NQ) { pre[j] = (pre[j] << 10) | sh_bin[j]; kk[j] = sh_kk[j]; }
+        }
+    }
+    // ---------------------------------------------------------------- the row's first chunk: result, workspace back to zero
+    if (s == 0) {
+        if (n == 0) {
+            if (tid < NQ) a.out[(int64_t)tid * a.R + r] = NAN;
+        } else {
+            // the next non-empty third-level bin above the selected one (the partner when the selected key is not repeated)
+#pragma unroll
+            for (int j = 0; j < QMAX; ++j)
+#pragma unroll
+                for (int u = 0; u < BPT1; ++u)
+                    if (j < NQ && hv2[j][u] != 0 && (unsigned)(BPT1 * tid + u) > sh_bin[j]) atomicMin(&sh_next[j], (unsigned)(BPT1 * tid + u));
+            __syncthreads();
+            if (tid < NQ) {
+                const int j = tid;
+                const float rank = a.q[j] * (float)(n - 1);
+                const float lo_f = floorf(rank), w = rank - lo_f;
+                const unsigned key_lo = (pre[j] << 10) | sh_bin[j];
+                const float v_lo = key2f(key_lo);
+                float v_hi = v_lo;
+                if (w != 0.f) {
+                    const unsigned mult = ld_agent(&g2[j * QB1 + sh_bin[j]]);
+                    if (sh_kk[j] + 1 >= mult) {            // the element of rank lo + 1 is a larger key
+                        const unsigned ab = ld_agent(&jobs.above[rt * QMAX + j]);
+                        if (sh_next[j] != QNONE) v_hi = key2f((pre[j] << 10) | sh_next[j]);
+                        else if (ab != 0u) v_hi = key2f(~ab);
+                    }
+                }
+                const float dlt = v_hi - v_lo;               // at::lerp: w < 0.5 ? a + w*(b-a) : b - (b-a)*(1-w)
+                a.out[(int64_t)j * a.R + r] = (w < 0.5f) ? v_lo + w * dlt : v_hi - dlt * (1.f - w);
+            }
+        }
+        if (a.mean_out && tid == 0) {
+            double t = 0;
+            for (int i = 0; i < G; ++i) t += __hip_atomic_load(&jobs.sums[rt * QCOOP_CHUNKS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a.mean_out[r] = (n == (unsigned)a.N) ? (float)(t / (double)a.N) : NAN;     // a NaN element makes torch's mean NaN
+        }
+        __syncthreads();
+        for (int i = tid; i < QMAX * QB1; i += QT1) g2[i] = 0u;
+        if (tid < QMAX) jobs.above[rt * QMAX + tid] = 0u;
+        if (tid < QCOOP_CHUNKS) jobs.sums[rt * QCOOP_CHUNKS + tid] = 0.0;
+    }
+    // the last chunk to leave re-arms the row's counters (nobody reads them any more)
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        if (atomicAdd(&sel[1], 1u) == (unsigned)G - 1u) { atomicExch(&sel[0], 0u); atomicExch(&sel[1], 0u); }
+    }
+}
+
 static int quant_check(const QuantArgs& a) {
     if (!a.x || !a.q || !a.out) return CP2_ERR_NULL;
     if (a.R <= 0 || a.N <= 0 || a.NQ <= 0) return CP2_ERR_SHAPE;
     if (a.NQ > QMAX) return CP2_ERR_UNSUPPORTED;
     if (a.want >= 0 && (!a.mask_a || !a.mask_b || a.P <= 0 || (int64_t)a.P * a.P != a.N)) return CP2_ERR_SHAPE;
-    if (a.mean_out && (a.want >= 0 || a.N > QROW_MAX)) return CP2_ERR_UNSUPPORTED;
+    if (a.mean_out && (a.want >= 0 || a.N > QROW_MAX)) return CP2_ERR_UNSUPPORTED;      // (the chunked three-level form has no sums)
     return CP2_OK;
 }
 
@@ -585,7 +798,7 @@ static int64_t quant_ws_words(int njobs, const int* R, const int* N, int NQ) {
     int64_t rows = 0;
     for (int j = 0; j < njobs; ++j)
         if (R[j] > 0 && N[j] > 0) rows += R[j];
-    return rows * QROW_WORDS;
+    return rows * QROW_WORDS + 2;                          // + alignment slack for the doubles behind an odd word count
 }
 
 CP2_API int64_t cp2_quantiles_workspace_bytes(int njobs, const int* R, const int* N, int NQ) {
@@ -596,6 +809,35 @@ CP2_API int64_t cp2_quantiles_workspace_bytes(int njobs, const int* R, const int
 static int quant_launch(QuantJobs& jobs, int njobs, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
     bool small = true;
     for (int j = 0; j < njobs; ++j) small = small && jobs.job[j].N <= QROW_MAX;
+    int64_t coop_wgs = 0;
+    for (int j = 0; j < njobs; ++j) coop_wgs += (int64_t)jobs.job[j].R * cp2_cdiv(jobs.job[j].N > 0 ? jobs.job[j].N : 1, QCHUNK);
+    if (small && workspace && coop_wgs <= QCOOP_MAX_WGS) { // one launch, one workgroup per chunk, row-local barriers
+        if (!cp2_aligned16(workspace)) return CP2_ERR_ALIGN;
+        int rows = 0, chunks = 0;
+        int Rs[QJOBS], Ns[QJOBS];
+        for (int j = 0; j < njobs; ++j) {
+            QuantArgs& a = jobs.job[j];
+            int rc = quant_check(a);
+            if (rc) return rc;
+            a.chunks = cp2_cdiv(a.N, QCHUNK);
+            jobs.first_row[j] = rows;
+            jobs.first_chunk[j] = chunks;
+            rows += a.R;
+            chunks += a.R * a.chunks;
+            Rs[j] = a.R; Ns[j] = a.N;
+        }
+        for (int j = njobs; j <= QJOBS; ++j) { jobs.first_row[j] = rows; jobs.first_chunk[j] = chunks; }
+        if (4 * quant_ws_words(njobs, Rs, Ns, jobs.job[0].NQ) > workspace_bytes) return CP2_ERR_SHAPE;
+        unsigned* w = static_cast<unsigned*>(workspace);
+        jobs.hist0 = w;
+        jobs.hist1 = jobs.hist0 + (int64_t)rows * QB0;
+        jobs.hist2 = jobs.hist1 + (int64_t)rows * QMAX * QB1;
+        jobs.above = jobs.hist2 + (int64_t)rows * QMAX * QB1;
+        jobs.sel = jobs.above + (int64_t)rows * QMAX;
+        jobs.sums = reinterpret_cast<double*>(jobs.sel + (int64_t)rows * QSEL + (((int64_t)rows * (QMAX + QSEL)) & 1));   // 8-byte aligned
+        CP2_LAUNCH_PROFILED(quantiles_coop_kernel, dim3(chunks), dim3(QT1), 0, stream, jobs);
+        return cp2_launch_status();
+    }
     if (small) {                                           // one launch, one workgroup per row, no workspace
         size_t lds = 0;
         int rows = 0;

@@ -713,13 +713,15 @@ def _quartile_tensor(device) -> torch.Tensor:
 
 _QUANT_WS = {}
 QUANTILES_ROW_MAX = 131072     # CP2_QUANTILES_ROW_MAX
+QUANTILES_CHUNK = 8192         # QCHUNK in csrc/quantile.hip
+QUANTILES_COOP_MAX_WGS = 768   # QCOOP_MAX_WGS: up to this many chunk workgroups the one-launch cooperative form is taken
 
 
 def _quant_workspace(dev, R, N, NQ):
     """Zeroed workspace of cp2_masked_quantiles(_multi), one per (device, shape signature): the kernels leave it zero,
     so it is allocated and cleared once (a few MB at the training shapes) and re-used by every later step."""
     import ctypes
-    key = (dev.index, tuple(R), tuple(N), NQ)
+    key = (dev.index, _stream(), tuple(R), tuple(N), NQ)     # per stream: two streams never share counters
     ws = _QUANT_WS.get(key)
     if ws is None:
         n = len(R)
@@ -764,8 +766,12 @@ def masked_quantiles_multi(jobs, q: Optional[torch.Tensor] = None):
             raise _lib.Cp2LibraryError("masked_quantiles: x must be a float32 GPU tensor")
     ma = [_opt(j.get("mask_a"), "mask_a", torch.float32) for j in jobs]
     mb = [_opt(j.get("mask_b"), "mask_b", torch.float32) for j in jobs]
-    # rows of at most QUANTILES_ROW_MAX elements: one launch, no workspace; longer rows: the chunked three-launch path
-    ws = None if all(j["N"] <= QUANTILES_ROW_MAX for j in jobs) else \
+    # rows of at most QUANTILES_ROW_MAX elements: one launch -- one workgroup per 8192-element chunk with row-local
+    # barriers when the call is small enough for every chunk to be resident (the training step), else one workgroup per
+    # row and no workspace (DenseCL's thousands of rows); longer rows: the chunked six-launch path
+    small = all(j["N"] <= QUANTILES_ROW_MAX for j in jobs)
+    coop = small and sum(j["R"] * -(-j["N"] // QUANTILES_CHUNK) for j in jobs) <= QUANTILES_COOP_MAX_WGS
+    ws = None if (small and not coop) else \
         _quant_workspace(dev, [j["R"] for j in jobs], [j["N"] for j in jobs], q.numel())
     _profile("quantiles")
     rc = lib.cp2_masked_quantiles_multi(

@@ -51,6 +51,62 @@ def test_compose_and_gathers_golden(golden_dir, name):
     assert np.array_equal(iou.cpu().numpy(), g["pixel_iou"]) and np.array_equal(ioum.cpu().numpy(), g["pixel_iou_masked"])
 
 
+@pytest.mark.parametrize("name", ["cp2_b4_64_k64", "cp2_b4_96_k64_wrap_bg", "cp2_b3_80x112_k1024"])
+def test_compose_pair_and_strided_iou_golden(golden_dir, name):
+    """The training step's forms against the reference's goldens: both views composed in one launch (bit-exact images
+    and down-sampled masks), and the IoUs read from the FULL-resolution id maps (the strided slices folded in)."""
+    g = load(golden_dir, name)
+    stride = int(g["cfg"][4])
+    out_a, out_b, md_a, md_b = ops.compose_pair(G(g["in_img_a"]), G(g["in_bg0"]), G(g["in_img_b"]), G(g["in_bg1"]), stride)
+    b = out_a.shape[0]
+    assert np.array_equal(out_a.cpu().numpy(), g["img_a"]) and np.array_equal(out_b.cpu().numpy(), g["img_b"])
+    assert np.array_equal(md_a.reshape(b, -1).cpu().numpy(), g["mask_a"]) and np.array_equal(md_b.reshape(b, -1).cpu().numpy(), g["mask_b"])
+    for kind, iou_key, ioum_key in (("region_ids", "iou", "iou_masked"), ("pixel_ids", "pixel_iou", "pixel_iou_masked")):
+        iou, ioum = ops.corr_iou_strided(G(g[f"in_{kind}_a"]), G(g[f"in_{kind}_b"]), stride, md_a.reshape(b, -1), md_b.reshape(b, -1))
+        assert np.array_equal(iou.cpu().numpy(), g[iou_key]) and np.array_equal(ioum.cpu().numpy(), g[ioum_key]), kind
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_compose_pair_layouts_shuffle_and_bf16(channels_last, dtype):
+    """compose_pair at the bench shape: the key view written in shuffle order (out_b[j] = composed_b[perm[j]], reference
+    builder.py:630), masks in the original order, channels-last memory, and bf16 = torch's round-to-nearest-even cast
+    of the exact fp32 composition (what autocast hands the stem convolution)."""
+    b, h, w, stride = 32, 224, 224, 16
+    gen = torch.Generator().manual_seed(9)
+    img_a, img_b = torch.rand(b, 3, h, w, generator=gen), torch.rand(b, 3, h, w, generator=gen)
+    bg0, bg1 = synth_bg(b, h, w, gen), synth_bg(b, h, w, gen)
+    img_a[0, 0, 0, 0] = float("inf")
+    perm = torch.randperm(b, generator=gen)
+    want_a, m_a = O.compose_mask(img_a, bg0)
+    want_b, m_b = O.compose_mask(img_b, bg1)
+    out_a, out_b, md_a, md_b = ops.compose_pair(img_a.to(DEV), bg0.to(DEV), img_b.to(DEV), bg1.to(DEV), stride, perm.to(DEV),
+                                                channels_last, dtype)
+    assert out_a.dtype == dtype and out_a.shape == (b, 3, h, w)
+    assert out_a.is_contiguous(memory_format=torch.channels_last if channels_last else torch.contiguous_format)
+    assert np.array_equal(out_a.float().cpu().numpy(), want_a.to(dtype).float().numpy(), equal_nan=True)
+    assert np.array_equal(out_b.float().cpu().numpy(), O.shuffle_take(want_b, perm, 0, 1).to(dtype).float().numpy())
+    assert torch.equal(md_a.cpu(), O.strided_gather(m_a, stride)) and torch.equal(md_b.cpu(), O.strided_gather(m_b, stride))
+    with pytest.raises(Exception):
+        ops.compose_pair(img_a[..., :222].contiguous().to(DEV), bg0[..., :222].contiguous().to(DEV),
+                         img_b[..., :222].contiguous().to(DEV), bg1[..., :222].contiguous().to(DEV), stride)   # W % 4 != 0
+
+
+def test_corr_iou_strided_equals_sliced_maps():
+    gen = torch.Generator().manual_seed(3)
+    for (b, h, w, s) in ((32, 224, 224, 16), (5, 50, 37, 8), (3, 64, 64, 32), (2, 20, 24, 1)):
+        a = torch.randint(0, 40, (b, h, w), generator=gen)
+        c = torch.randint(0, 40, (b, h, w), generator=gen)
+        da, dc = O.strided_gather(a, s), O.strided_gather(c, s)
+        p = da[0].numel()
+        ma, mb = (torch.rand(b, p, generator=gen) > 0.4).float(), (torch.rand(b, p, generator=gen) > 0.5).float()
+        iou, ioum = ops.corr_iou_strided(a.to(DEV), c.to(DEV), s, ma.to(DEV), mb.to(DEV))
+        ref_iou, ref_ioum = ops.corr_iou(da.contiguous().to(DEV), dc.contiguous().to(DEV), ma.to(DEV), mb.to(DEV))
+        assert torch.equal(iou, ref_iou) and torch.equal(torch.isnan(ioum), torch.isnan(ref_ioum))
+        assert torch.equal(torch.nan_to_num(ioum, nan=-1.0), torch.nan_to_num(ref_ioum, nan=-1.0))
+        assert torch.equal(iou.cpu(), O.masked_iou(da.reshape(b, -1), dc.reshape(b, -1), torch.ones(b, p), torch.ones(b, p)))
+
+
 @pytest.mark.parametrize("shape,stride", [((32, 224, 224), 16), ((3, 50, 37), 8), ((2, 17, 21), 1), ((2, 64, 66), 32)])
 def test_compose_full_size_vs_oracle(shape, stride):
     b, h, w = shape

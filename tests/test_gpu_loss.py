@@ -118,6 +118,87 @@ def test_feat_kernels_vs_oracle_and_channels_last():
         assert_close(extras[:, 1], (pos_ref * neg_ref).sum(1), 3e-6, what="extras")
 
 
+@pytest.mark.parametrize("fmt", [torch.contiguous_format, torch.channels_last])
+def test_feat_pair_with_row_index_equals_two_single_launches(fmt):
+    """cp2_feat_normalize_pool_pair (query + key in one launch, key rows through the un-shuffle index, channels-last maps
+    staged through LDS) == the two single-map launches on a gathered key map, bit for bit; P = 196 (a ragged last tile)."""
+    gen = torch.Generator().manual_seed(1)
+    B, C, h, w = 7, 128, 14, 14
+    qf = torch.randn(B, C, h, w, generator=gen).to(DEV).contiguous(memory_format=fmt)
+    kf = torch.randn(B, C, h, w, generator=gen).to(DEV).contiguous(memory_format=fmt)
+    ma = (torch.rand(B, h * w, generator=gen) > 0.4).float().to(DEV)
+    mb = (torch.rand(B, h * w, generator=gen) > 0.6).float().to(DEV)
+    perm = torch.randperm(B, generator=gen).to(DEV)
+    qd, kd, inv, qp, kp = ops.feat_normalize_pool_pair(qf, kf, ma, mb, perm)
+    rq = ops.feat_normalize_pool(qf, ma)
+    rk = ops.feat_normalize_pool(kf[perm].contiguous(memory_format=fmt), mb)
+    assert torch.equal(qd, rq[0]) and torch.equal(inv, rq[1]) and torch.equal(qp, rq[2])
+    assert torch.equal(kd, rk[0]) and torch.equal(kp, rk[2])
+    qd2, kd2, _, _, kp2 = ops.feat_normalize_pool_pair(qf, kf, ma, mb, None)
+    rk2 = ops.feat_normalize_pool(kf, mb)
+    assert torch.equal(kd2, rk2[0]) and torch.equal(kp2, rk2[2]) and torch.equal(qd2, qd)
+
+
+@pytest.mark.parametrize("fmt,inc_bg,S", [(torch.contiguous_format, False, 1), (torch.channels_last, True, 4), (torch.channels_last, False, 3)])
+def test_feat_bwd_fused_equals_separate_launches(fmt, inc_bg, S):
+    """cp2_feat_bwd_fused == dense_grad_sum (split order) + cp2_pool_bwd + cp2_feat_bwd, bit for bit."""
+    gen = torch.Generator().manual_seed(2)
+    B, C, h, w = 6, 128, 14, 14
+    P = h * w
+    feat = torch.randn(B, C, h, w, generator=gen).to(DEV).contiguous(memory_format=fmt)
+    mask = (torch.rand(B, P, generator=gen) > 0.4).float().to(DEV)
+    dense, inv, part = ops.feat_normalize_pool(feat, mask)
+    q_pos, q_neg, q_norms, k_pos, k_neg, _ = ops.pool_finalize(part, part.flip(0).contiguous(), P)
+    g_part = torch.randn(S, B, C, P, generator=gen).to(DEV)
+    drows = torch.randn(B, C, generator=gen).to(DEV)
+    NE = 3 if inc_bg else 1
+    dE = torch.randn(B, NE, generator=gen).to(DEV)
+    got = ops.feat_bwd_fused(dense, inv, mask, g_part if S > 1 else g_part[0].contiguous(), S, drows, dE, q_pos, q_neg, k_pos, k_neg,
+                             q_norms, inc_bg, feat)
+    g = g_part[0].clone()
+    for sidx in range(1, S):
+        g = g + g_part[sidx]
+    dE3 = torch.zeros(B, 3, device=DEV)
+    dE3[:, :NE] = dE
+    ds_pos, ds_neg = ops.pool_bwd(drows, dE3, q_pos, q_neg, k_pos, k_neg, q_norms, inc_bg)
+    want = ops.feat_bwd(dense, inv, mask, g, ds_pos, ds_neg, feat)
+    assert got.stride() == feat.stride() and torch.equal(got, want)
+
+
+def test_step_scalars_vs_torch():
+    """Every returned / logged scalar of the step from one launch, against the torch expressions round 2 ran
+    (reference builder.py:1431-1448, 1265, 1282, 1553-1604)."""
+    gen = torch.Generator().manual_seed(4)
+    B, C = 32, 128
+    ins_loss = torch.rand((), generator=gen) * 8
+    cnt = torch.randint(0, 9, (B,), generator=gen, dtype=torch.int32)
+    extras = torch.randn(B, 3, generator=gen)
+    sample = torch.rand(B, 8, generator=gen)
+    sample[:, 5] = (sample[:, 5] > 0.5).float()
+    q_pos = torch.nn.functional.normalize(torch.randn(B, C, generator=gen), dim=1)
+    k_pos = torch.nn.functional.normalize(torch.randn(B, C, generator=gen), dim=1)
+    quart = [torch.randn(3, B, generator=gen) for _ in range(3)]
+    lmean = torch.randn(B, generator=gen)
+    lam = 0.2
+    d = lambda t: t.to(DEV)  # noqa: E731
+    out = ops.step_scalars(d(ins_loss), d(cnt), d(extras), d(sample), d(q_pos), d(k_pos), lam, d(quart[0]), d(quart[1]), d(quart[2]),
+                           d(lmean)).cpu()
+    l_den = sample[:, 2].mean()
+    want = {0: ins_loss + l_den * lam, 1: ins_loss, 2: l_den, 3: (cnt < 1).float().mean() * 100, 4: (cnt < 5).float().mean() * 100,
+            5: sample[:, 5].mean() * 100, 6: sample[:, 3].mean(), 7: sample[:, 4].mean(), 8: extras[:, 0].mean(),
+            9: q_pos.std(0).mean(), 10: k_pos.std(0).mean(), 20: lmean.mean()}
+    for j in range(3):
+        for k in range(3):
+            want[11 + 3 * j + k] = quart[j][k].mean()
+    for i, v in want.items():
+        assert abs(float(out[i]) - float(v)) <= 2e-6 * max(1.0, abs(float(v))), (i, float(out[i]), float(v))
+    # NaN in a sample's loss propagates as torch's mean does; absent quartiles read as zero
+    sample[3, 2] = float("nan")
+    out2 = ops.step_scalars(d(ins_loss), d(cnt), d(extras[:, :1].contiguous()), d(sample), d(q_pos), d(k_pos), lam).cpu()
+    assert torch.isnan(out2[0]) and torch.isnan(out2[2]) and float(out2[11]) == 0.0 and float(out2[20]) == 0.0
+    assert abs(float(out2[8]) - float(extras[:, 0].mean())) <= 2e-6
+
+
 def _rand_case(B, hw, K, seed, stride_fmt=torch.contiguous_format):
     gen = torch.Generator().manual_seed(seed)
     h, w = hw
