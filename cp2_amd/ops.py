@@ -714,6 +714,7 @@ def _quartile_tensor(device) -> torch.Tensor:
 _QUANT_WS = {}
 QUANTILES_ROW_MAX = 131072     # CP2_QUANTILES_ROW_MAX
 QUANTILES_CHUNK = 8192         # QCHUNK in csrc/quantile.hip
+QUANTILES_COOP = True          # A/B switch (tools/bench_quantiles.py): False = one workgroup per row
 QUANTILES_COOP_MAX_WGS = 768   # QCOOP_MAX_WGS: up to this many chunk workgroups the one-launch cooperative form is taken
 
 
@@ -770,7 +771,7 @@ def masked_quantiles_multi(jobs, q: Optional[torch.Tensor] = None):
     # barriers when the call is small enough for every chunk to be resident (the training step), else one workgroup per
     # row and no workspace (DenseCL's thousands of rows); longer rows: the chunked six-launch path
     small = all(j["N"] <= QUANTILES_ROW_MAX for j in jobs)
-    coop = small and sum(j["R"] * -(-j["N"] // QUANTILES_CHUNK) for j in jobs) <= QUANTILES_COOP_MAX_WGS
+    coop = small and QUANTILES_COOP and sum(j["R"] * -(-j["N"] // QUANTILES_CHUNK) for j in jobs) <= QUANTILES_COOP_MAX_WGS
     ws = None if (small and not coop) else \
         _quant_workspace(dev, [j["R"] for j in jobs], [j["N"] for j in jobs], q.numel())
     _profile("quantiles")

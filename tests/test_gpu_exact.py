@@ -57,7 +57,10 @@ def test_compose_pair_and_strided_iou_golden(golden_dir, name):
     and down-sampled masks), and the IoUs read from the FULL-resolution id maps (the strided slices folded in)."""
     g = load(golden_dir, name)
     stride = int(g["cfg"][4])
-    out_a, out_b, md_a, md_b = ops.compose_pair(G(g["in_img_a"]), G(g["in_bg0"]), G(g["in_img_b"]), G(g["in_bg1"]), stride)
+    # the reference's local img_b is the key batch AFTER shuffle-BN (builder.py:1274): the golden holds it in that order,
+    # which is what compose_pair writes when it is given the permutation
+    perm = torch.argsort(torch.from_numpy(g["idx_unshuffle"])).to(DEV)
+    out_a, out_b, md_a, md_b = ops.compose_pair(G(g["in_img_a"]), G(g["in_bg0"]), G(g["in_img_b"]), G(g["in_bg1"]), stride, perm)
     b = out_a.shape[0]
     assert np.array_equal(out_a.cpu().numpy(), g["img_a"]) and np.array_equal(out_b.cpu().numpy(), g["img_b"])
     assert np.array_equal(md_a.reshape(b, -1).cpu().numpy(), g["mask_a"]) and np.array_equal(md_b.reshape(b, -1).cpu().numpy(), g["mask_b"])
