@@ -56,6 +56,8 @@ def parse():
     p.add_argument("--flat-sgd", default="on", choices=["on", "off"],
                    help="optimizer step as one HIP launch on the flat parameter buffer (off: torch.optim.SGD) (A/B)")
     p.add_argument("--fused-bn", default="on", choices=["on", "off"], help="encoder fast path: fused BN(+add)(+ReLU) kernels (A/B)")
+    p.add_argument("--bn-launches", default="2", choices=["2", "3"],
+                   help="fused BN as statistics (fp64 atomics) + apply, or with round 2's finalize launch in between (A/B)")
     p.add_argument("--overlap", default="auto", choices=["auto", "gather", "on", "off"],
                    help="side HIP stream for the key branch: gather = EMA + shuffle exchange only (auto when N > 1), "
                         "on = the key encoder too, off = serial (auto at N = 1)")
@@ -192,6 +194,7 @@ def main():
     from cp2_amd import builder, ops, synthetic
     from cp2_amd.encoder import FusedBatchNorm2d
     FusedBatchNorm2d.fused = args.fused_bn == "on"
+    FusedBatchNorm2d.two_launch = args.bn_launches == "2"
     from cp2_amd.encoder import StemMaxPool
     StemMaxPool.fused = args.fused_bn == "on" and os.environ.get("CP2_STEM_POOL", "1") == "1"   # same encoder fast path (env: A/B)
     from cp2_amd.encoder import Conv2d

@@ -590,19 +590,22 @@ __device__ __forceinline__ unsigned ld_agent(const unsigned* p) {
 }
 
 // All chunks of the row have arrived `target` times in total.  Returns false on time-out (flag raised).
+// No agent-scope fence: everything the chunks exchange is written by agent-scope atomics and read by agent-scope atomic
+// loads (performed at the device's coherence point), and __syncthreads() -- a workgroup-scope release, i.e. "every memory
+// operation of the workgroup has completed" -- stands between a chunk's last histogram add and its arrival.  A
+// __threadfence() here is an L2 write-back + invalidate per workgroup and barrier: measured 144 us for the launch
+// against 63 us for the one-workgroup-per-row kernel it replaces.
 __device__ __forceinline__ bool row_barrier(unsigned* sel, unsigned target) {
     __shared__ int ok;
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();                                   // this chunk's histogram adds are performed before the arrival
         atomicAdd(&sel[0], 1u);
         unsigned spins = 0;
         bool good = true;
         while (ld_agent(&sel[0]) < target) {
-            __builtin_amdgcn_s_sleep(4);
+            __builtin_amdgcn_s_sleep(2);
             if (++spins > (1u << 22)) { atomicExch(&sel[2], 1u); good = false; break; }
         }
-        __threadfence();
         ok = good;
     }
     __syncthreads();
@@ -778,10 +781,7 @@ __global__ __launch_bounds__(QT1, 3) void quantiles_coop_kernel(QuantJobs jobs) 
     }
     // the last chunk to leave re-arms the row's counters (nobody reads them any more)
     __syncthreads();
-    if (tid == 0) {
-        __threadfence();
-        if (atomicAdd(&sel[1], 1u) == (unsigned)G - 1u) { atomicExch(&sel[0], 0u); atomicExch(&sel[1], 0u); }
-    }
+    if (tid == 0 && atomicAdd(&sel[1], 1u) == (unsigned)G - 1u) { atomicExch(&sel[0], 0u); atomicExch(&sel[1], 0u); }
 }
 
 static int quant_check(const QuantArgs& a) {

@@ -292,7 +292,11 @@ class MirrorModule(nn.Module):
         confusion counts (binary task: class 1 is the positive; multi-class: class 0 ignored, as the reference sets
         ignore_index).  torchmetrics is not installed, so these follow the textbook definitions (unpinned)."""
         buf = getattr(self, f"confusion_{stage.name.lower()}")
-        c = buf.double().cpu()
+        counts = buf.clone()
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(counts)                      # every rank counted its own shard (torchmetrics' dist_sync_on_step=False + sync at compute)
+        c = counts.double().cpu()
         if reset:
             buf.zero_()
         fg = slice(1, None)

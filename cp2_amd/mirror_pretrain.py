@@ -109,6 +109,12 @@ def _load_images(args, device):
     return tr, va
 
 
+def shard_len(n: int, world: int, batch: int) -> int:
+    """Samples per rank and epoch: the same on every rank and, when the data allow it, a whole number of batches."""
+    per_rank = n // world
+    return (per_rank // batch) * batch if per_rank >= batch else per_rank
+
+
 def main(args):
     import torch.distributed as dist
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
@@ -137,13 +143,18 @@ def main(args):
     # the reference's Trainer(sync_batchnorm=True) (:231) is not reproduced: BatchNorm statistics stay per rank
     step_mod = model
     if world > 1:
-        step_mod = torch.nn.parallel.DistributedDataParallel(_StepWrapper(model), device_ids=[local])
+        # broadcast_buffers=False: the confusion counts are per-rank tallies (summed over ranks in MirrorModule.metrics);
+        # DDP's default would overwrite them with rank 0's on every forward
+        step_mod = torch.nn.parallel.DistributedDataParallel(_StepWrapper(model), device_ids=[local], broadcast_buffers=False)
     optimizer = model.configure_optimizers()["optimizer"]
     best, b = float("inf"), args.batch_size
     for epoch in range(args.epochs):
         model.train()
         perm = torch.randperm(len(train_u8), generator=torch.Generator().manual_seed(args.seed + epoch)).tolist()
-        perm = perm[rank::world]
+        # equal shards on every rank (Lightning's DistributedSampler pads; here the tail that does not fill one batch on every
+        # rank is dropped): a rank with one more step than its peers would wait for a gradient all-reduce that never comes
+        per_rank = shard_len(len(perm), world, b)
+        perm = perm[rank:per_rank * world:world]
         nb = max(1, len(perm) // b) if not args.fast_dev_run else 1
         for i in range(nb):
             batch = M.cutpaste_batch(train_u8, train_s, perm[i * b:(i + 1) * b])

@@ -312,3 +312,16 @@ def test_gpu_mirror_ops_reject_cpu_tensors():
         ops.cutpaste(torch.zeros(2, 8, 8, 3, dtype=torch.uint8), None, torch.zeros(2, 20, dtype=torch.int32))
     with pytest.raises(_lib.Cp2LibraryError):
         ops.mirror_loss(torch.zeros(1, 2, 4, 4), None, torch.zeros(1, 4, 4, dtype=torch.int64), 2.0, 0.1)
+
+
+def test_ddp_shards_have_the_same_number_of_steps_on_every_rank():
+    """ADVICE r2: perm[rank::world] gave ranks different step counts when len(train) % world != 0 (one rank then waits for
+    an all-reduce its peers never start).  Every rank now takes the same number of samples, whole batches when possible."""
+    from cp2_amd.mirror_pretrain import shard_len
+    for n, world, b in ((103, 4, 5), (17, 2, 8), (64, 8, 8), (9, 4, 8), (1000, 3, 16)):
+        per = shard_len(n, world, b)
+        shards = [list(range(n))[r:per * world:world] for r in range(world)]
+        assert len({len(s_) for s_ in shards}) == 1 and len(shards[0]) == per
+        assert per <= n // world and (per % b == 0 or per < b)
+        flat = [i for s_ in shards for i in s_]
+        assert len(set(flat)) == len(flat)                          # disjoint
