@@ -56,8 +56,6 @@ def parse():
     p.add_argument("--flat-sgd", default="on", choices=["on", "off"],
                    help="optimizer step as one HIP launch on the flat parameter buffer (off: torch.optim.SGD) (A/B)")
     p.add_argument("--fused-bn", default="on", choices=["on", "off"], help="encoder fast path: fused BN(+add)(+ReLU) kernels (A/B)")
-    p.add_argument("--bn-launches", default="2", choices=["2", "3"],
-                   help="fused BN as statistics (fp64 atomics) + apply, or with round 2's finalize launch in between (A/B)")
     p.add_argument("--overlap", default="auto", choices=["auto", "gather", "on", "off"],
                    help="side HIP stream for the key branch: gather = EMA + shuffle exchange only (auto when N > 1), "
                         "on = the key encoder too, off = serial (auto at N = 1)")
@@ -194,7 +192,6 @@ def main():
     from cp2_amd import builder, ops, synthetic
     from cp2_amd.encoder import FusedBatchNorm2d
     FusedBatchNorm2d.fused = args.fused_bn == "on"
-    FusedBatchNorm2d.two_launch = args.bn_launches == "2"
     from cp2_amd.encoder import StemMaxPool
     StemMaxPool.fused = args.fused_bn == "on" and os.environ.get("CP2_STEM_POOL", "1") == "1"   # same encoder fast path (env: A/B)
     from cp2_amd.encoder import Conv2d
@@ -298,7 +295,8 @@ def main():
             nosync_ms = dt_ns / args.nosync_steps * 1e3
             exposed = round(dt / args.steps * 1e3 - nosync_ms, 4)
         n_grad = sum(p.numel() for p in model.parameters() if p.requires_grad)
-        img_row, key_row = 3 * hw * hw * 4, 128 * (hw // model.output_stride) ** 2 * 4
+        # composed images travel as cp2_compose_pair wrote them: bf16 under bf16 autocast (W % 4 == 0), else fp32
+        img_row, key_row = 3 * hw * hw * (2 if (amp is not None and hw % 4 == 0) else 4), 128 * (hw // model.output_stride) ** 2 * 4
         frac = (world - 1) / world
         comm = {
             "backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(), "one_device_rehearsal": bool(args.one_device),

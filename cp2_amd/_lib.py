@@ -62,8 +62,6 @@ SIGNATURES = {
     "cp2_bn_num_partials": [c_int, c_int],
     "cp2_bn_fwd": [_P, _P, _P, _P, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P],
     "cp2_bn_bwd": [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, _P],
-    "cp2_bn_fwd2": [_P, _P, _P, _P, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, c_int, c_int, _P],
-    "cp2_bn_bwd2": [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P],
     "cp2_masked_quantiles": [_P, c_int64, c_int64, c_int, c_int, _P, _P, c_int, c_int, _P, c_int, _P, _P, c_int64, _P],
     "cp2_quantiles_workspace_bytes": [c_int, _P, _P, c_int],
     "cp2_masked_quantiles_multi": [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int64, _P],

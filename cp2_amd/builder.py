@@ -331,7 +331,6 @@ class MODEL(nn.Module):
         self._side_stream = None
         self.key_forward_graph = True    # replay the (gradient-free) key encoder forward from a hipGraph after warm-up
         self._key_graph = None
-        self._key_bn_pool = None
         self._pending_logs = []          # device scalars waiting for one batched device->host copy
         self.shuffle_exchange = "all_to_all"   # shuffle-BN rows by all-to-all; "all_gather" = the reference's form
         self.comm_events = None          # bench.py: {} -> every exchange step records a (start, stop) event pair
@@ -438,18 +437,7 @@ class MODEL(nn.Module):
                 # a captured call does not execute: take back the lazy num_batches_tracked ticks it made
                 capturing = torch.cuda.is_current_stream_capturing()
                 before = [m._pending_batches for m in bns] if capturing else None
-                if capturing:
-                    # the fused BN's fp64 accumulators of a captured forward come from a pool of its own whose fill is the
-                    # first node of the graph: every replay finds them zero (ops.BnAccPool)
-                    if self._key_bn_pool is None:
-                        self._key_bn_pool = ops.BnAccPool(x.device, words=1 << 18)
-                    self._key_bn_pool.rewind_and_zero()
-                    ops.BN_POOL_OVERRIDE = self._key_bn_pool
-                try:
-                    out = self._encode(self.encoder_k, x)
-                finally:
-                    if capturing:
-                        ops.BN_POOL_OVERRIDE = None
+                out = self._encode(self.encoder_k, x)
                 if capturing:
                     fwd.fused = [m for m, b in zip(bns, before) if m._pending_batches != b]
                     for m, b in zip(bns, before):

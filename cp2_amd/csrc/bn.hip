@@ -74,11 +74,11 @@ __device__ __forceinline__ void bn_bwd_channel(const BnFin& f, int c, int M, int
 // apply workgroups of small layers add the partials themselves: the load -> LDS -> math -> LDS prologue costs what the
 // finalize launch costs, 5.6 -> 9.4 us per forward apply, and the 32-chunk cap it needs slows the statistics kernels.)
 // ---------------------------------------------------------------------------------------------------------------
-template <int MODE, bool RELU, bool ATOMIC = false>
+template <int MODE, bool RELU>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const u16x8* __restrict__ x, const u16x8* __restrict__ dy,
                                                        const u16x8* __restrict__ y, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, float* __restrict__ part,
-                                                       BnGeom g, double* __restrict__ acc_d = nullptr) {
+                                                       BnGeom g) {
     __shared__ float red[256][17];
     constexpr int U = MODE == 0 ? 4 : 2;          // rows in flight per thread
     const int tid = threadIdx.x, cgl = tid % g.CGs, rl = tid / g.CGs;
@@ -128,11 +128,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const u16x8* __restrict__
         const int s = tid / SC, ch = tid % SC;
         float acc = 0.f;
         for (int k = 0; k < g.RP; ++k) acc += red[k * g.CGs + (ch >> 3)][s * 8 + (ch & 7)];
-        // ATOMIC (two-launch form): the per-channel sums are accumulated in fp64 in a caller-zeroed buffer [2][C] instead
-        // of being written as partial rows for a finalize launch; fp32 partials are exact in fp64 and at most 256 of them
-        // meet per channel, so the order of arrival moves the sum by ~1e-16 relative -- below what the fp32 results keep
-        if (ATOMIC) unsafeAtomicAdd(&acc_d[(int64_t)s * g.C + slice * SC + ch], (double)acc);
-        else part[((int64_t)chunk * 2 + s) * g.C + slice * SC + ch] = acc;
+        part[((int64_t)chunk * 2 + s) * g.C + slice * SC + ch] = acc;
     }
 }
 
@@ -266,151 +262,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const u16x8* __restri
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Two-launch form (round 3): statistics with fp64 atomics (bn_stats_kernel<.., ATOMIC>) + an apply whose prologue does
-// what bn_finalize_kernel did -- one thread per channel of the workgroup's slice turns the two sums into the
-// per-channel constants and leaves them in LDS; the workgroups of row chunk 0 also store what the finalize launch
-// stored (saved statistics, running statistics / dgamma, dbeta).  168 launches of ~4.8 us per step disappear.
-// ---------------------------------------------------------------------------------------------------------------
-template <bool RELU, bool RES>
-__global__ __launch_bounds__(256) void bn_fwd_apply2_kernel(const u16x8* __restrict__ x, const u16x8* __restrict__ res,
-                                                            const double* __restrict__ acc, BnFin f, u16x8* __restrict__ y,
-                                                            BnGeom g) {
-    constexpr int U = RES ? 2 : 4;
-    __shared__ float lsc[128], lsh[128];
-    const int tid = threadIdx.x, cgl = tid % g.CGs, rl = tid / g.CGs;
-    const int slice = blockIdx.x % g.NS, chunk = blockIdx.x / g.NS;
-    const int cg = slice * g.CGs + cgl;
-    const int SC = g.CGs * 8;
-    const int r0 = chunk * g.rpb;
-    const int r1 = min(g.M, r0 + g.rpb);
-    // the first rows' loads are in flight while the per-channel constants are formed
-    u16x8 xv[U], rv[U];
-    int r = r0 + rl;
-    if (r < r1) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int rr = r + u * g.RP;
-            const int64_t o = (int64_t)(rr < r1 ? rr : r) * g.CG + cg;
-            xv[u] = x[o];
-            if (RES) rv[u] = res[o];
-        }
-    }
-    if (tid < SC) {
-        const int c = slice * SC + tid;
-        const double s = acc[c], ss = acc[g.C + c];
-        const double mean = s / g.M;
-        double var = ss / g.M - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
-        const float gam = f.weight ? f.weight[c] : 1.f, bet = f.bias ? f.bias[c] : 0.f;
-        const float sc = gam * invstd;
-        lsc[tid] = sc;
-        lsh[tid] = bet - (float)mean * sc;
-        if (chunk == 0) {
-            f.o2[c] = (float)mean;
-            f.o3[c] = invstd;
-            if (f.running_mean) f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mean;
-            if (f.running_var) {
-                const double unbiased = g.M > 1 ? var * (double)g.M / (double)(g.M - 1) : var;
-                f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unbiased;
-            }
-        }
-    }
-    __syncthreads();
-    float sc[8], sh[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { sc[j] = lsc[cgl * 8 + j]; sh[j] = lsh[cgl * 8 + j]; }
-    for (; r < r1; r += g.RP * U) {
-        if (r != r0 + rl) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int rr = r + u * g.RP;
-                const int64_t o = (int64_t)(rr < r1 ? rr : r) * g.CG + cg;
-                xv[u] = x[o];
-                if (RES) rv[u] = res[o];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int rr = r + u * g.RP;
-            if (rr >= r1) break;
-            u16x8 out;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float v = bf2f(xv[u][j]) * sc[j] + sh[j];
-                if (RES) v += bf2f(rv[u][j]);
-                if (RELU) v = fmaxf(v, 0.f);
-                out[j] = f2bf(v);
-            }
-            y[(int64_t)rr * g.CG + cg] = out;
-        }
-    }
-}
-
-template <bool RELU, bool DRES>
-__global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const u16x8* __restrict__ x, const u16x8* __restrict__ dy,
-                                                            const u16x8* __restrict__ y, const float* __restrict__ mean,
-                                                            const float* __restrict__ invstd, const double* __restrict__ acc,
-                                                            const float* __restrict__ weight, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, u16x8* __restrict__ dx,
-                                                            u16x8* __restrict__ dres, BnGeom g) {
-    constexpr int U = 2;
-    __shared__ float lc[3][128];
-    const int tid = threadIdx.x, cgl = tid % g.CGs, rl = tid / g.CGs;
-    const int slice = blockIdx.x % g.NS, chunk = blockIdx.x / g.NS;
-    const int cg = slice * g.CGs + cgl;
-    const int SC = g.CGs * 8;
-    if (tid < SC) {
-        const int c = slice * SC + tid;
-        const double s = acc[c], sx = acc[g.C + c];
-        lc[0][tid] = (weight ? weight[c] : 1.f) * invstd[c];
-        lc[1][tid] = (float)(s / g.M);
-        lc[2][tid] = (float)(sx / g.M);
-        if (chunk == 0) {
-            if (dbeta) dbeta[c] = (float)s;
-            if (dgamma) dgamma[c] = (float)sx;
-        }
-    }
-    float mu[8], is[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { mu[j] = mean[cg * 8 + j]; is[j] = invstd[cg * 8 + j]; }
-    __syncthreads();
-    float c0[8], c1[8], c2[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { c0[j] = lc[0][cgl * 8 + j]; c1[j] = lc[1][cgl * 8 + j]; c2[j] = lc[2][cgl * 8 + j]; }
-    const int r0 = chunk * g.rpb;
-    const int r1 = min(g.M, r0 + g.rpb);
-    for (int r = r0 + rl; r < r1; r += g.RP * U) {
-        u16x8 xv[U], dv[U], yv[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int rr = r + u * g.RP;
-            const int64_t o = (int64_t)(rr < r1 ? rr : r) * g.CG + cg;
-            xv[u] = x[o];
-            dv[u] = dy[o];
-            if (RELU) yv[u] = y[o];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int rr = r + u * g.RP;
-            if (rr >= r1) break;
-            u16x8 ox, og;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float gg = bf2f(dv[u][j]);
-                if (RELU && !(bf2f(yv[u][j]) > 0.f)) gg = 0.f;
-                const float xh = (bf2f(xv[u][j]) - mu[j]) * is[j];
-                ox[j] = f2bf(c0[j] * (gg - c1[j] - xh * c2[j]));
-                og[j] = f2bf(gg);
-            }
-            const int64_t o = (int64_t)rr * g.CG + cg;
-            dx[o] = ox;
-            if (DRES) dres[o] = og;
-        }
-    }
-}
-
 // Geometry: channel slices of 128 (64 when C is not a multiple of 128) channels, `target` workgroups in all, every
 // thread at least 4 rows, at most max_chunks row chunks (bn_finalize_kernel adds at most 256 partials per channel).
 static int bn_geom(int M, int C, int target, int max_chunks, BnGeom* g) {
@@ -490,57 +341,5 @@ CP2_API int cp2_bn_bwd(const void* x, const void* dy, const void* y, const float
     else if (relu) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false>), grid, dim3(256), 0, s, xv, dv, yv, save_mean, save_invstd, coef, ox, og, ga);
     else if (dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true>), grid, dim3(256), 0, s, xv, dv, yv, save_mean, save_invstd, coef, ox, og, ga);
     else hipLaunchKernelGGL((bn_bwd_apply_kernel<false, false>), grid, dim3(256), 0, s, xv, dv, yv, save_mean, save_invstd, coef, ox, og, ga);
-    return cp2_launch_status();
-}
-
-// Two-launch forms: `acc` is a caller-owned fp64 buffer [2][C] that is ZERO on entry and holds the two per-channel sums
-// afterwards (the caller hands every call a fresh zeroed slice; cp2_amd/encoder.py keeps a pool that one fill launch
-// re-zeroes every few steps).  Outputs and arithmetic as cp2_bn_fwd / cp2_bn_bwd (fp64 combine; the sums are accumulated
-// by atomics instead of in a fixed order).
-CP2_API int cp2_bn_fwd2(const void* x, const void* residual, const float* weight, const float* bias, float* running_mean,
-                        float* running_var, float momentum, float eps, int relu, void* y, float* save_mean,
-                        float* save_invstd, double* acc, int M, int C, void* stream) {
-    if (!x || !y || !save_mean || !save_invstd || !acc) return CP2_ERR_NULL;
-    BnGeom gs, ga;
-    int rc = bn_geom_stats(M, C, &gs);
-    if (rc) return rc;
-    bn_geom_apply(M, C, &ga);
-    if (!bn_al(x) || !bn_al(y) || (residual && !bn_al(residual))) return CP2_ERR_ALIGN;
-    const u16x8* xv = static_cast<const u16x8*>(x);
-    const u16x8* rv = static_cast<const u16x8*>(residual);
-    hipStream_t s = cp2_stream(stream);
-    const BnFin f{weight, bias, running_mean, running_var, momentum, eps, nullptr, nullptr, save_mean, save_invstd, nullptr};
-    hipLaunchKernelGGL((bn_stats_kernel<0, false, true>), dim3(gs.Gr * gs.NS), dim3(256), 0, s, xv, nullptr, nullptr, nullptr,
-                       nullptr, nullptr, gs, acc);
-    u16x8* yv = static_cast<u16x8*>(y);
-    const dim3 grid(ga.Gr * ga.NS);
-    if (relu && residual) hipLaunchKernelGGL((bn_fwd_apply2_kernel<true, true>), grid, dim3(256), 0, s, xv, rv, acc, f, yv, ga);
-    else if (relu) hipLaunchKernelGGL((bn_fwd_apply2_kernel<true, false>), grid, dim3(256), 0, s, xv, rv, acc, f, yv, ga);
-    else if (residual) hipLaunchKernelGGL((bn_fwd_apply2_kernel<false, true>), grid, dim3(256), 0, s, xv, rv, acc, f, yv, ga);
-    else hipLaunchKernelGGL((bn_fwd_apply2_kernel<false, false>), grid, dim3(256), 0, s, xv, rv, acc, f, yv, ga);
-    return cp2_launch_status();
-}
-
-CP2_API int cp2_bn_bwd2(const void* x, const void* dy, const void* y, const float* weight, const float* save_mean,
-                        const float* save_invstd, int relu, void* dx, void* dres, float* dgamma, float* dbeta, double* acc,
-                        int M, int C, void* stream) {
-    if (!x || !dy || !dx || !save_mean || !save_invstd || !acc) return CP2_ERR_NULL;
-    if (relu && !y) return CP2_ERR_NULL;
-    BnGeom gs, ga;
-    int rc = bn_geom_stats(M, C, &gs);
-    if (rc) return rc;
-    bn_geom_apply(M, C, &ga);
-    if (!bn_al(x) || !bn_al(dy) || !bn_al(dx) || (y && !bn_al(y)) || (dres && !bn_al(dres))) return CP2_ERR_ALIGN;
-    const u16x8 *xv = static_cast<const u16x8*>(x), *dv = static_cast<const u16x8*>(dy), *yv = static_cast<const u16x8*>(y);
-    hipStream_t s = cp2_stream(stream);
-    const dim3 sgrid(gs.Gr * gs.NS);
-    if (relu) hipLaunchKernelGGL((bn_stats_kernel<1, true, true>), sgrid, dim3(256), 0, s, xv, dv, yv, save_mean, save_invstd, nullptr, gs, acc);
-    else hipLaunchKernelGGL((bn_stats_kernel<1, false, true>), sgrid, dim3(256), 0, s, xv, dv, yv, save_mean, save_invstd, nullptr, gs, acc);
-    u16x8 *ox = static_cast<u16x8*>(dx), *og = static_cast<u16x8*>(dres);
-    const dim3 grid(ga.Gr * ga.NS);
-    if (relu && dres) hipLaunchKernelGGL((bn_bwd_apply2_kernel<true, true>), grid, dim3(256), 0, s, xv, dv, yv, save_mean, save_invstd, acc, weight, dgamma, dbeta, ox, og, ga);
-    else if (relu) hipLaunchKernelGGL((bn_bwd_apply2_kernel<true, false>), grid, dim3(256), 0, s, xv, dv, yv, save_mean, save_invstd, acc, weight, dgamma, dbeta, ox, og, ga);
-    else if (dres) hipLaunchKernelGGL((bn_bwd_apply2_kernel<false, true>), grid, dim3(256), 0, s, xv, dv, yv, save_mean, save_invstd, acc, weight, dgamma, dbeta, ox, og, ga);
-    else hipLaunchKernelGGL((bn_bwd_apply2_kernel<false, false>), grid, dim3(256), 0, s, xv, dv, yv, save_mean, save_invstd, acc, weight, dgamma, dbeta, ox, og, ga);
     return cp2_launch_status();
 }

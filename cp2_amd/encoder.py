@@ -34,8 +34,7 @@ class _FusedBNFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, running_mean, running_var, momentum, eps, relu):
         ops = _bn_ops
-        fwd = ops.bn_fwd2 if FusedBatchNorm2d.two_launch else ops.bn_fwd
-        y, stats = fwd(x, residual, weight, bias, running_mean, running_var, momentum, eps, relu)
+        y, stats = ops.bn_fwd(x, residual, weight, bias, running_mean, running_var, momentum, eps, relu)
         ctx.save_for_backward(x, y if relu else None, weight, stats)
         ctx.relu, ctx.has_res = relu, residual is not None
         return y
@@ -46,8 +45,7 @@ class _FusedBNFn(torch.autograd.Function):
         x, y, weight, stats = ctx.saved_tensors
         if dy.dtype != torch.bfloat16 or not dy.is_contiguous(memory_format=torch.channels_last):
             dy = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        bwd = ops.bn_bwd2 if FusedBatchNorm2d.two_launch else ops.bn_bwd
-        dx, dres, dgamma, dbeta = bwd(x, dy, y, weight, stats, ctx.relu, ctx.has_res)
+        dx, dres, dgamma, dbeta = ops.bn_bwd(x, dy, y, weight, stats, ctx.relu, ctx.has_res)
         return dx, dgamma, dbeta, dres, None, None, None, None, None
 
 
@@ -58,8 +56,6 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
     matters when momentum is None, which is never fused)."""
 
     fused = True            # class-wide switch (bench.py --fused-bn off for A/B)
-    two_launch = True       # statistics (fp64 atomics) + apply with the per-channel combine in its prologue; False: the
-                            # three-launch form with a finalize kernel in between (bench.py --bn-launches 3 for A/B)
 
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)

@@ -714,7 +714,9 @@ def _quartile_tensor(device) -> torch.Tensor:
 _QUANT_WS = {}
 QUANTILES_ROW_MAX = 131072     # CP2_QUANTILES_ROW_MAX
 QUANTILES_CHUNK = 8192         # QCHUNK in csrc/quantile.hip
-QUANTILES_COOP = True          # A/B switch (tools/bench_quantiles.py): False = one workgroup per row
+QUANTILES_COOP = False         # one workgroup per chunk with row-local barriers: measured 59.6 us vs 63.3 us for the
+                               # workgroup-per-row kernel at the step's shapes -- not worth a spin-wait in the product path; kept
+                               # for tools/bench_quantiles.py and the parity tests
 QUANTILES_COOP_MAX_WGS = 768   # QCOOP_MAX_WGS: up to this many chunk workgroups the one-launch cooperative form is taken
 
 
@@ -844,84 +846,6 @@ def bn_bwd(x, dy, y, weight, stats, relu: bool, want_dres: bool):
     if want_dres and not relu:
         dres = dy
     return dx, dres, ws[2 * G + 3], ws[2 * G + 4]
-
-
-class BnAccPool:
-    """Zeroed fp64 slices for the two-launch BN forms (cp2_bn_fwd2 / cp2_bn_bwd2): every call takes the next 2*C doubles
-    of a pool that ONE fill launch re-zeroes when it is used up (every ~10 training steps), instead of one zero-fill or
-    finalize launch per BatchNorm call.  One pool per (device, stream): a refill is ordered after every earlier user of
-    the slices on that stream."""
-
-    WORDS = 1 << 21                # 16 MiB of doubles
-
-    def __init__(self, device, words: Optional[int] = None):
-        self.buf = torch.zeros(words or self.WORDS, dtype=torch.float64, device=device)
-        self.at = 0
-
-    def take(self, n: int) -> torch.Tensor:
-        if n > self.buf.numel():
-            raise ValueError("BnAccPool: request larger than the pool")
-        if self.at + n > self.buf.numel():
-            self.buf.zero_()
-            self.at = 0
-        out = self.buf[self.at:self.at + n]
-        self.at += n
-        return out
-
-    def rewind_and_zero(self):
-        """Start of a captured region: the region's calls take slices from the start of the pool, and the fill that
-        precedes them is part of the capture, so every replay finds them zero."""
-        self.buf.zero_()
-        self.at = 0
-
-
-_BN_POOLS = {}
-BN_POOL_OVERRIDE = None            # a BnAccPool private to a hipGraph capture (engine.ForwardGraph users set it)
-
-
-def bn_acc(device, n: int) -> torch.Tensor:
-    if BN_POOL_OVERRIDE is not None:
-        return BN_POOL_OVERRIDE.take(n)
-    key = (torch.device(device).index, _stream())
-    pool = _BN_POOLS.get(key)
-    if pool is None:
-        pool = _BN_POOLS[key] = BnAccPool(device)
-    return pool.take(n)
-
-
-def bn_fwd2(x, residual, weight, bias, running_mean, running_var, momentum: float, eps: float, relu: bool):
-    """bn_fwd in two launches (statistics with fp64 atomics + apply); returns (y, stats[2,C] = save_mean, save_invstd)."""
-    lib = _lib.load()
-    N, C, H, W = x.shape
-    M = N * H * W
-    y = torch.empty_like(x)
-    stats = torch.empty((2, C), dtype=torch.float32, device=x.device)
-    acc = bn_acc(x.device, 2 * C)
-    rc = lib.cp2_bn_fwd2(x.data_ptr(), residual.data_ptr() if residual is not None else None, weight.data_ptr(), bias.data_ptr(),
-                         running_mean.data_ptr(), running_var.data_ptr(), momentum, eps, int(relu), y.data_ptr(),
-                         stats.data_ptr(), stats.data_ptr() + 4 * C, acc.data_ptr(), M, C, _stream())
-    if rc:
-        _lib.check(rc, "cp2_bn_fwd2")
-    return y, stats
-
-
-def bn_bwd2(x, dy, y, weight, stats, relu: bool, want_dres: bool):
-    lib = _lib.load()
-    N, C, H, W = x.shape
-    M = N * H * W
-    dx = torch.empty_like(x)
-    dres = torch.empty_like(x) if (want_dres and relu) else None
-    dgb = torch.empty((2, C), dtype=torch.float32, device=x.device)
-    acc = bn_acc(x.device, 2 * C)
-    sp = stats.data_ptr()
-    rc = lib.cp2_bn_bwd2(x.data_ptr(), dy.data_ptr(), y.data_ptr() if relu else None, weight.data_ptr(), sp, sp + 4 * C,
-                         int(relu), dx.data_ptr(), dres.data_ptr() if dres is not None else None, dgb.data_ptr(),
-                         dgb.data_ptr() + 4 * C, acc.data_ptr(), M, C, _stream())
-    if rc:
-        _lib.check(rc, "cp2_bn_bwd2")
-    if want_dres and not relu:
-        dres = dy
-    return dx, dres, dgb[0], dgb[1]
 
 
 # ---------------------------------------------------------------- encoder fast path: 1x1 convolution weight gradient

@@ -332,16 +332,7 @@ int cp2_bn_fwd(const void* x, const void* residual, const float* weight, const f
 int cp2_bn_bwd(const void* x, const void* dy, const void* y, const float* weight, const float* save_mean,
                const float* save_invstd, int relu, void* dx, void* dres, float* dgamma, float* dbeta, float* part,
                float* coef, int M, int C, void* stream);
-/* Two-launch forms (statistics + apply; the per-channel combine that cp2_bn_fwd / cp2_bn_bwd run as a third launch is the
- * apply kernel's prologue).  acc: caller-owned double[2, C], ZERO on entry, holds the two per-channel sums afterwards (hand
- * every call a fresh zeroed slice).  The sums are accumulated with fp64 atomics: the order of arrival moves them by ~1e-16
- * relative, below what the fp32 results keep.  Everything else as above. */
-int cp2_bn_fwd2(const void* x, const void* residual, const float* weight, const float* bias, float* running_mean,
-                float* running_var, float momentum, float eps, int relu, void* y, float* save_mean, float* save_invstd,
-                double* acc, int M, int C, void* stream);
-int cp2_bn_bwd2(const void* x, const void* dy, const void* y, const float* weight, const float* save_mean,
-                const float* save_invstd, int relu, void* dx, void* dres, float* dgamma, float* dbeta, double* acc, int M,
-                int C, void* stream);
+
 
 /* ---- encoder fast path (not a reference call site): weight gradient of a 1x1 stride-1 convolution ---------------
  * dw[co][ci] = sum_m dy[m][co] * x[m][ci];  dy: [M, CO] bf16, x: [M, CI] bf16 (channels-last activations viewed as

@@ -12,16 +12,6 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-@pytest.fixture(params=[True, False], ids=["two-launch", "three-launch"])
-def bn_form(request):
-    """Both forms of the fused BN: statistics by fp64 atomics + apply with the per-channel combine in its prologue
-    (default), and round 2's statistics -> finalize -> apply."""
-    old = FusedBatchNorm2d.two_launch
-    FusedBatchNorm2d.two_launch = request.param
-    yield request.param
-    FusedBatchNorm2d.two_launch = old
-
-
 def close(got, want, rel, what):
     got, want = got.float().cpu(), want.float().cpu()
     err = (got - want).abs().max().item()
@@ -32,7 +22,7 @@ def close(got, want, rel, what):
 @pytest.mark.parametrize("N,C,H,W", [(32, 64, 56, 56), (5, 256, 7, 9), (32, 2048, 14, 14), (3, 128, 1, 1), (2, 512, 13, 5),
                                      (4, 192, 9, 9), (32, 1024, 14, 14), (8, 256, 56, 56)])
 @pytest.mark.parametrize("relu,use_res", [(True, False), (True, True), (False, False), (False, True)])
-def test_fused_bn_matches_fp32_batchnorm(N, C, H, W, relu, use_res, bn_form):
+def test_fused_bn_matches_fp32_batchnorm(N, C, H, W, relu, use_res):
     torch.manual_seed(C + H)
     x = (torch.randn(N, C, H, W, device=DEV) * 1.7 + 0.3).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     res = torch.randn(N, C, H, W, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) if use_res else None
@@ -72,10 +62,8 @@ def test_fused_bn_matches_fp32_batchnorm(N, C, H, W, relu, use_res, bn_form):
     assert set(sd) == set(ref.state_dict()) and int(sd["num_batches_tracked"]) == 1
 
 
-def test_fused_bn_is_run_to_run_identical(bn_form):
-    """Three-launch form: partial sums are combined in a fixed order (no atomics), repeated launches are bit-identical by
-    construction.  Two-launch form: the fp64 atomics meet in any order, which moves a sum by ~1e-16 relative -- a factor 1e8
-    below the fp32 rounding of the constants derived from it, so repeated launches are bit-identical in practice as well."""
+def test_fused_bn_is_run_to_run_identical():
+    """Partial sums are combined in a fixed order (no atomics): repeated launches are bit-identical."""
     torch.manual_seed(1)
     outs = []
     for C, H in ((64, 56), (2048, 14), (256, 28)):
@@ -104,35 +92,3 @@ def test_fallback_paths_match_stock_batchnorm():
     fused.eval(); ref.eval()
     xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)   # eval mode -> stock path
     assert torch.equal(fused(xb), ref(xb))
-
-
-def test_two_launch_form_gets_a_zeroed_accumulator_every_call():
-    """The two-launch form relies on every call finding its fp64 accumulator slice zero: a pool that holds only three
-    slices is re-zeroed by its refill after every third call (and a capture-private pool by the fill at the head of the
-    captured region); ten calls in a row through such pools all reproduce the three-launch result."""
-    from cp2_amd import ops
-    torch.manual_seed(3)
-    C = 128
-    x = (torch.randn(8, C, 14, 14, device=DEV) * 2 + 1).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    up = torch.randn_like(x)
-    old_form, old_pool = FusedBatchNorm2d.two_launch, ops.BN_POOL_OVERRIDE
-    try:
-        FusedBatchNorm2d.two_launch = False
-        ref = FusedBatchNorm2d(C).to(DEV).train()
-        xr = x.clone().requires_grad_(True)
-        yr = ref(xr, relu=True)
-        yr.backward(up)
-        FusedBatchNorm2d.two_launch = True
-        ops.BN_POOL_OVERRIDE = ops.BnAccPool(DEV, words=3 * 2 * C + 5)       # forward + backward = 2 slices per iteration
-        bn = FusedBatchNorm2d(C).to(DEV).train()
-        for it in range(10):
-            if it == 6:
-                ops.BN_POOL_OVERRIDE.rewind_and_zero()                           # what a captured region does at its head
-            xf = x.clone().requires_grad_(True)
-            bn.zero_grad()
-            y = bn(xf, relu=True)
-            y.backward(up)
-            assert torch.equal(y, yr) and torch.equal(xf.grad, xr.grad), it
-            assert torch.equal(bn.weight.grad, ref.weight.grad) and torch.equal(bn.bias.grad, ref.bias.grad), it
-    finally:
-        FusedBatchNorm2d.two_launch, ops.BN_POOL_OVERRIDE = old_form, old_pool

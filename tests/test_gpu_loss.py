@@ -313,9 +313,29 @@ def test_rowkey_large_split_property():
     grad_close(got.dE[:, 0], p_cpu.grad, "slice d pos")
 
 
-def test_masked_quantiles_bit_exact_vs_torch():
+@pytest.mark.parametrize("coop", [False, True], ids=["row-kernel", "chunk-cooperative"])
+def test_masked_quantiles_bit_exact_vs_torch(coop):
     """Same input -> the radix-select quantiles equal torch.quantile / torch.nanquantile bit for bit
-    (the reference's convention, tests/test_contrastive_metrics.py:50-57)."""
+    (the reference's convention, tests/test_contrastive_metrics.py:50-57).  Both one-launch forms for rows up to 131072
+    elements: a workgroup per row (the product path) and a workgroup per chunk with row-local barriers (kept as an option:
+    6 % faster at the step's shapes), plus the row means torch's x.mean(1) gives."""
+    old = ops.QUANTILES_COOP
+    ops.QUANTILES_COOP = coop
+    try:
+        _masked_quantiles_cases()
+        gen = torch.Generator().manual_seed(8)
+        x = torch.randn(6, 70_001, generator=gen)
+        x[2, 17] = float("nan")
+        means = torch.empty(6, device=DEV)
+        q = ops.masked_quantiles_multi([dict(x=x.to(DEV), stride_row=70_001, stride_elem=1, R=6, N=70_001, mean_out=means)])[0]
+        assert np.array_equal(q.cpu().numpy(), torch.nanquantile(x, torch.tensor([0.25, 0.5, 0.75]), dim=1).numpy(), equal_nan=True)
+        want = x.double().mean(1).float()
+        assert torch.isnan(means[2]) and (means.cpu()[[0, 1, 3, 4, 5]] - want[[0, 1, 3, 4, 5]]).abs().max() <= 1e-6
+    finally:
+        ops.QUANTILES_COOP = old
+
+
+def _masked_quantiles_cases():
     kat = torch.tensor([[1., 2, 3, 4, 5, 6], [1, 2, 3, 7, 8, 9]])
     got = ops.masked_quantiles(kat.to(DEV), 6, 1, 2, 6)
     assert torch.equal(got.cpu(), torch.tensor([[2.25, 2.25], [3.5, 5.0], [4.75, 7.75]]))
