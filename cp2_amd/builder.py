@@ -577,8 +577,13 @@ class MODEL(nn.Module):
             row_b = plan.device_tables(img_a.device)[0]                    # send order
         elif not multi:
             if idx_shuffle is None:
-                idx_shuffle = cdist.make_shuffle_index(b, img_a.device)
-            idx_unshuffle = torch.argsort(idx_shuffle)
+                # one rank: permutation and its inverse on the host (the global torch RNG, as builder.py:618), one copy --
+                # a device argsort is a sort kernel plus four helper launches per step
+                host = torch.randperm(b)
+                both = torch.stack([host, torch.argsort(host)]).to(img_a.device, non_blocking=True)
+                idx_shuffle, idx_unshuffle = both[0], both[1]
+            else:
+                idx_unshuffle = torch.argsort(idx_shuffle)
             row_b = idx_shuffle.contiguous()
         else:
             row_b = None                                                   # the reference's all-gather form shuffles after the gather

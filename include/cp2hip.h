@@ -11,7 +11,8 @@
  *
  * Conventions (every function):
  *   - raw DEVICE pointers + explicit sizes; the caller owns all memory, the
- *     library allocates nothing, keeps no state and never synchronises the host;
+ *     library allocates nothing, keeps no state (one documented exception:
+ *     cp2_profile_next_launch) and never synchronises the host;
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); every
  *     kernel is enqueued on it, so calls are hipGraph-capturable;
  *   - return value: 0 = ok, <0 = argument error (CP2_ERR_*), >0 = hipError_t of
@@ -42,7 +43,9 @@ const char* cp2_error_string(int code);
 
 /* Measurement aid: the next launch of the dominant kernel of cp2_rowkey_infonce_fwd, cp2_dense_infonce_fwd / _bwd,
  * cp2_masked_quantiles(_multi) or cp2_sgd_flat made by the calling thread carries these caller-owned hipEvent_t
- * (start, stop), so hipEventElapsedTime gives that kernel's own duration.  One shot; NULL, NULL disarms. */
+ * (start, stop), so hipEventElapsedTime gives that kernel's own duration.  One shot; NULL, NULL disarms.
+ * The ONE exception to "the library keeps no state": a thread-local pair of event handles, consumed (and cleared) by the
+ * next profiled launch of the same thread.  bench.py only; nothing is armed in normal operation. */
 int cp2_profile_next_launch(void* start_event, void* stop_event);
 
 /* ---- a1 (+ mask part of a2): copy-paste composition ---- builder.py:1146-1159
