@@ -225,10 +225,16 @@ __global__ __launch_bounds__(256) void blur_tensor_kernel(const uint32_t* __rest
     uint32_t* Bf = lds + (kTile + 2 * halo) * (kTile + 2 * halo);
     const uint32_t* src = img + (int64_t)b * H * W;
     const int gy0 = ty0 - hl, gx0 = tx0 - hl;
-    for (int e = threadIdx.x; e < RW * RH; e += 256) {
-        const int ry = e / RW, rx = e % RW;
-        const int gy = min(max(gy0 + ry, 0), H - 1), gx = min(max(gx0 + rx, 0), W - 1);
-        A[e] = src[(int64_t)gy * W + gx];
+    // thread layouts without a division: loads and horizontal passes walk rows of up to 64 columns (RW <= 62) four at a
+    // time; vertical passes only need the tile's 32 columns and walk them eight rows at a time
+    const int hx = threadIdx.x & 63, hy = threadIdx.x >> 6;
+    const int vx = threadIdx.x & 31, vy = threadIdx.x >> 5;
+    if (hx < RW) {
+        const int gx = min(max(gx0 + hx, 0), W - 1);
+        for (int ry = hy; ry < RH; ry += 4) {
+            const int gy = min(max(gy0 + ry, 0), H - 1);
+            A[ry * RW + hx] = src[(int64_t)gy * W + gx];
+        }
     }
     __syncthreads();
     if (on) {
@@ -236,25 +242,28 @@ __global__ __launch_bounds__(256) void blur_tensor_kernel(const uint32_t* __rest
         uint32_t* o = Bf;
         for (int pass = 0; pass < 6; ++pass) {
             const bool horiz = pass < 3;
-            for (int e = threadIdx.x; e < RW * RH; e += 256) {
-                const int ry = e / RW, rx = e % RW;
-                const int g = horiz ? gx0 + rx : gy0 + ry;         // global coordinate along the pass axis
-                const int n = horiz ? W : H, g0 = horiz ? gx0 : gy0, R = horiz ? RW : RH;
-                if (g < 0 || g >= n) continue;
+            const int n = horiz ? W : H, g0 = horiz ? gx0 : gy0, R = horiz ? RW : RH;
+            const int cx = horiz ? hx : vx + hl;           // column of this thread in the region
+            const int step = horiz ? 4 : 8;
+            const bool col_ok = horiz ? hx < RW : true;
+            // the tap positions along the pass axis depend on the thread's fixed coordinate only for horizontal passes
+            for (int ry = horiz ? hy : vy; ry < RH; ry += step) {
+                const int g = horiz ? gx0 + cx : gy0 + ry;     // global coordinate along the pass axis
+                if (!col_ok || g < 0 || g >= n) continue;
                 uint32_t s0 = 0, s1 = 0, s2 = 0;
                 for (int d = -r; d <= r; ++d) {
                     const int l = min(max(min(max(g + d, 0), n - 1) - g0, 0), R - 1);
-                    const uint32_t v = horiz ? in[ry * RW + l] : in[l * RW + rx];
+                    const uint32_t v = horiz ? in[ry * RW + l] : in[l * RW + cx];
                     s0 += v & 255, s1 += (v >> 8) & 255, s2 += (v >> 16) & 255;
                 }
                 const int la = min(max(min(max(g - r - 1, 0), n - 1) - g0, 0), R - 1);
                 const int lb = min(max(min(max(g + r + 1, 0), n - 1) - g0, 0), R - 1);
-                const uint32_t va = horiz ? in[ry * RW + la] : in[la * RW + rx];
-                const uint32_t vb = horiz ? in[ry * RW + lb] : in[lb * RW + rx];
+                const uint32_t va = horiz ? in[ry * RW + la] : in[la * RW + cx];
+                const uint32_t vb = horiz ? in[ry * RW + lb] : in[lb * RW + cx];
                 const uint32_t f0 = (va & 255) + (vb & 255), f1 = ((va >> 8) & 255) + ((vb >> 8) & 255), f2 = ((va >> 16) & 255) + ((vb >> 16) & 255);
                 const uint32_t o0 = (s0 * ww + f0 * fw + (1u << 23)) >> 24, o1 = (s1 * ww + f1 * fw + (1u << 23)) >> 24,
                                o2 = (s2 * ww + f2 * fw + (1u << 23)) >> 24;
-                o[e] = (o0 & 255) | ((o1 & 255) << 8) | ((o2 & 255) << 16);
+                o[ry * RW + cx] = (o0 & 255) | ((o1 & 255) << 8) | ((o2 & 255) << 16);
             }
             __syncthreads();
             uint32_t* t = in;
