@@ -626,11 +626,11 @@ class MODEL(nn.Module):
             side.wait_stream(cur)
 
         def exchange_in(x):
-            """This rank's composed key images -> the rows its key encoder takes."""
+            """This rank's composed key images -> (the rows its key encoder takes, what exchange_out needs to undo it)."""
             if a2a:
                 with self._comm("c1_image_exchange"):
                     rows, restore = _rows_as_f32(x)
-                    return restore(cdist.exchange_rows(rows, plan, take=ops.gather_rows, presorted=fused))
+                    return restore(cdist.exchange_rows(rows, plan, take=ops.gather_rows, presorted=fused)), None
             if multi:
                 return self._batch_shuffle_ddp(x, idx_shuffle)
             return x, None                                   # one rank: compose_pair wrote the rows in shuffled order
@@ -652,10 +652,7 @@ class MODEL(nn.Module):
                 self._momentum_update_key_encoder()
             if side is not cur and img_b.is_cuda:
                 img_b.record_stream(side)
-            if a2a:
-                img_k, ctx = exchange_in(img_b), None
-            else:
-                img_k, ctx = exchange_in(img_b)
+            img_k, ctx = exchange_in(img_b)
             if mode != "gather":
                 k, k_row = exchange_out(self._encode_key(img_k), ctx)
         q = self._encode(self.encoder_q, img_a).float()                          # queries: b x C x h x w
