@@ -60,13 +60,18 @@ def _worker(rank, world, port, out_dir):
             assert torch.equal(got, O.shuffle_take(g, perm, rank, world))
             back = cdist.exchange_rows(got * 2.0 + 1.0, plan, backward=True)
             assert torch.equal(back, x * 2.0 + 1.0)
+            # the forms the training step uses: the composition kernel already wrote the rows in send order (presorted),
+            # and the returned keys stay in arrival order -- the loss kernel reads sample i at row back_place[i] (keep_order)
+            assert torch.equal(cdist.exchange_rows(x[plan.send_rows], plan, presorted=True), got)
+            arrived = cdist.exchange_rows(got * 2.0 + 1.0, plan, backward=True, keep_order=True)
+            assert torch.equal(arrived[plan.back_place], x * 2.0 + 1.0)
             assert plan.bytes_received(16) == 16 * (b - plan.recv_counts[rank])
         # enqueue: every rank appends ALL ranks' keys in rank order -> replicas of the queue stay identical
-        K, C = 16, 4
+        K, C = 32, 4
         queue = torch.zeros(C, K)
-        ptr = 13                                           # crosses the wrap boundary
+        ptr = 29                                           # crosses the wrap boundary
         queue, ptr = O.dequeue_and_enqueue(queue, ptr, cdist.concat_all_gather(x))
-        assert ptr == (13 + world * b) % K
+        assert ptr == (29 + world * b) % K
         torch.save(queue, os.path.join(out_dir, f"q{rank}.pt"))
         dist.barrier()
     finally:
@@ -74,13 +79,13 @@ def _worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(120)
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_world_n_gloo_collectives(tmp_path, world):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     q0, q1 = torch.load(tmp_path / "q0.pt"), torch.load(tmp_path / "q1.pt")
     assert torch.equal(q0, q1)
     want = torch.cat([torch.arange(12, dtype=torch.float32).reshape(3, 4) + 1000 * r for r in range(world)])
-    cols = [(13 + i) % 16 for i in range(world * 3)]
+    cols = [(29 + i) % 32 for i in range(world * 3)]
     assert torch.equal(q0[:, cols], want.t())
 
 
