@@ -357,6 +357,10 @@ def main():
             ach = work / (ms * 1e-3) / (1e9 if unit == "GB/s" else 1e12)
             kernels.append({"kernel": kernel, "bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": unit,
                             "frac": round(ach / peak, 4), "avg_launch_us": round(ms * 1e3, 2), "work_per_launch": work, "note": note})
+    px_bytes = 4 * 3 * 4 + 2 * 3 * (2 if amp is not None else 4)      # per pixel: img_a, bg0, img_b, bg1 read in fp32; two views written
+    add("compose_pair", "compose_pair_kernel (copy-paste composition of both views, builder.py:1146-1159, key rows in shuffle order)", "hbm",
+        b * hw * hw * px_bytes, "GB/s", HBM_PEAK_GBS, "algorithmic bytes = 4 fp32 image reads + 2 composed views written (bf16 under autocast); "
+        "PMC traffic 1.002 x (profiles/compose_traffic.json)")
     add("rowkey_fwd", "rowkey_small_kernel (instance InfoNCE: q_pos x queue, builder.py:1395-1428)", "hbm", 4 * C * K, "GB/s",
         HBM_PEAK_GBS, "algorithmic bytes = the fp32 queue read once (4*C*K); with quartile logging on the launch also writes the b x K logits")
     add("dense_fwd", "dense_fwd_kernel (P x P logits + column soft-max statistics, builder.py:1289-1292,1431-1437)", "mfma", 2.0 * b * P * P * C,

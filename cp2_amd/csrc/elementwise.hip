@@ -207,7 +207,7 @@ CP2_API int cp2_compose_pair(const float* img_a, const float* bg0, const float* 
                       ds_size(H, stride), ds_size(W, stride), channels_last != 0, out_bf16 != 0};
     int blocks = cp2_cdiv((int64_t)2 * B * H * (W / 4), 256);
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(compose_pair_kernel, dim3(blocks), dim3(256), 0, cp2_stream(stream), a);
+    CP2_LAUNCH_PROFILED(compose_pair_kernel, dim3(blocks), dim3(256), 0, cp2_stream(stream), a);
     return cp2_launch_status();
 }
 

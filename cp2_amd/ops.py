@@ -98,6 +98,7 @@ def compose_pair(img_a, bg0, img_b, bg1, stride: int, row_b: Optional[torch.Tens
     md_b = torch.empty_like(md_a)
     if row_b is not None and (row_b.numel() != B or row_b.dtype != torch.int64):
         raise ValueError("compose_pair: row_b must hold B int64 indices")
+    _profile("compose_pair")
     rc = lib.cp2_compose_pair(_dev(img_a, "img_a", torch.float32), _dev(bg0, "bg0", torch.float32), _dev(img_b, "img_b", torch.float32),
                               _dev(bg1, "bg1", torch.float32), out_a.data_ptr(), out_b.data_ptr(), md_a.data_ptr(), md_b.data_ptr(),
                               _opt(row_b, "row_b", torch.int64), B, H, W, stride, int(channels_last),

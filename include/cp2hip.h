@@ -41,8 +41,8 @@ int cp2_version(void);
 /* Human-readable text for a return code of this library. */
 const char* cp2_error_string(int code);
 
-/* Measurement aid: the next launch of the dominant kernel of cp2_rowkey_infonce_fwd, cp2_dense_infonce_fwd / _bwd,
- * cp2_masked_quantiles(_multi) or cp2_sgd_flat made by the calling thread carries these caller-owned hipEvent_t
+/* Measurement aid: the next launch of the dominant kernel of cp2_compose_pair, cp2_rowkey_infonce_fwd,
+ * cp2_dense_infonce_fwd / _bwd, cp2_masked_quantiles(_multi) or cp2_sgd_flat made by the calling thread carries these caller-owned hipEvent_t
  * (start, stop), so hipEventElapsedTime gives that kernel's own duration.  One shot; NULL, NULL disarms.
  * The ONE exception to "the library keeps no state": a thread-local pair of event handles, consumed (and cleared) by the
  * next profiled launch of the same thread.  bench.py only; nothing is armed in normal operation. */
