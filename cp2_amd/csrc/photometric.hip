@@ -245,24 +245,42 @@ __global__ __launch_bounds__(256) void blur_tensor_kernel(const uint32_t* __rest
             const int n = horiz ? W : H, g0 = horiz ? gx0 : gy0, R = horiz ? RW : RH;
             const int cx = horiz ? hx : vx + hl;           // column of this thread in the region
             const int step = horiz ? 4 : 8;
-            const bool col_ok = horiz ? hx < RW : true;
-            // the tap positions along the pass axis depend on the thread's fixed coordinate only for horizontal passes
-            for (int ry = horiz ? hy : vy; ry < RH; ry += step) {
+            // pass k of an axis only has to produce what the remaining 2 - k passes of that axis will read: the region
+            // shrinks by r + 1 on both sides per pass (the last pass of an axis produces exactly the tile's extent)
+            const int shrink = ((horiz ? pass : pass - 3) + 1) * (r + 1);
+            const bool col_ok = horiz ? (hx >= shrink && hx < RW - shrink) : true;
+            const int row_lo = horiz ? 0 : shrink, row_hi = horiz ? RH : RH - shrink;
+            for (int ry = (horiz ? hy : vy) + (row_lo / step) * step; ry < row_hi; ry += step) {
+                if (ry < row_lo) continue;
                 const int g = horiz ? gx0 + cx : gy0 + ry;     // global coordinate along the pass axis
                 if (!col_ok || g < 0 || g >= n) continue;
-                uint32_t s0 = 0, s1 = 0, s2 = 0;
-                for (int d = -r; d <= r; ++d) {
-                    const int l = min(max(min(max(g + d, 0), n - 1) - g0, 0), R - 1);
-                    const uint32_t v = horiz ? in[ry * RW + l] : in[l * RW + cx];
-                    s0 += v & 255, s1 += (v >> 8) & 255, s2 += (v >> 16) & 255;
+                const int c = g - g0;                          // local coordinate along the pass axis
+                // R and B are summed side by side in one word (fields of 16 bits: at most 11 taps x 255), G in another
+                uint32_t srb = 0, sg = 0, frb, fg;
+                if (g - r - 1 >= 0 && g + r + 1 < n) {         // interior: no clamping (c - r - 1 >= 0 and c + r + 1 < R hold, see above)
+                    const uint32_t* q = horiz ? in + ry * RW + c : in + c * RW + cx;
+                    const int st = horiz ? 1 : RW;
+                    for (int d = -r; d <= r; ++d) {
+                        const uint32_t v = q[d * st];
+                        srb += v & 0x00FF00FFu, sg += (v >> 8) & 255u;
+                    }
+                    const uint32_t va = q[(-r - 1) * st], vb = q[(r + 1) * st];
+                    frb = (va & 0x00FF00FFu) + (vb & 0x00FF00FFu), fg = ((va >> 8) & 255u) + ((vb >> 8) & 255u);
+                } else {                                        // at an image edge: replicate, as ImagingLineBoxBlur does
+                    for (int d = -r; d <= r; ++d) {
+                        const int l = min(max(min(max(g + d, 0), n - 1) - g0, 0), R - 1);
+                        const uint32_t v = horiz ? in[ry * RW + l] : in[l * RW + cx];
+                        srb += v & 0x00FF00FFu, sg += (v >> 8) & 255u;
+                    }
+                    const int la = min(max(min(max(g - r - 1, 0), n - 1) - g0, 0), R - 1);
+                    const int lb = min(max(min(max(g + r + 1, 0), n - 1) - g0, 0), R - 1);
+                    const uint32_t va = horiz ? in[ry * RW + la] : in[la * RW + cx];
+                    const uint32_t vb = horiz ? in[ry * RW + lb] : in[lb * RW + cx];
+                    frb = (va & 0x00FF00FFu) + (vb & 0x00FF00FFu), fg = ((va >> 8) & 255u) + ((vb >> 8) & 255u);
                 }
-                const int la = min(max(min(max(g - r - 1, 0), n - 1) - g0, 0), R - 1);
-                const int lb = min(max(min(max(g + r + 1, 0), n - 1) - g0, 0), R - 1);
-                const uint32_t va = horiz ? in[ry * RW + la] : in[la * RW + cx];
-                const uint32_t vb = horiz ? in[ry * RW + lb] : in[lb * RW + cx];
-                const uint32_t f0 = (va & 255) + (vb & 255), f1 = ((va >> 8) & 255) + ((vb >> 8) & 255), f2 = ((va >> 16) & 255) + ((vb >> 16) & 255);
-                const uint32_t o0 = (s0 * ww + f0 * fw + (1u << 23)) >> 24, o1 = (s1 * ww + f1 * fw + (1u << 23)) >> 24,
-                               o2 = (s2 * ww + f2 * fw + (1u << 23)) >> 24;
+                const uint32_t o0 = ((srb & 0xFFFFu) * ww + (frb & 0xFFFFu) * fw + (1u << 23)) >> 24;
+                const uint32_t o1 = (sg * ww + fg * fw + (1u << 23)) >> 24;
+                const uint32_t o2 = ((srb >> 16) * ww + (frb >> 16) * fw + (1u << 23)) >> 24;
                 o[ry * RW + cx] = (o0 & 255) | ((o1 & 255) << 8) | ((o2 & 255) << 16);
             }
             __syncthreads();
