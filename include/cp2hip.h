@@ -87,6 +87,8 @@ int cp2_corr_iou(const int64_t* ids_a, const int64_t* ids_b, const float* mask_a
  * at (s/2 + s*i, s/2 + s*j); masks are already down-sampled, [B, Hs*Ws]. */
 int cp2_corr_iou_strided(const int64_t* ids_a, const int64_t* ids_b, const float* mask_a, const float* mask_b,
                          float* iou, float* iou_masked, int B, int H, int W, int stride, void* stream);
+/* (Up to 2047 cells per map the keys are counted in an LDS hash table -- two barriers; above that they are sorted by a
+ * bitonic network.  Identical counts either way.) */
 
 /* ---- a11: momentum (EMA) update of the key encoder -------- builder.py:557-567
  * k[i] = k[i]*m + q[i]*one_minus_m  (two rounded products, one rounded sum; no FMA).

@@ -138,7 +138,9 @@ def test_corr_iou_kats(golden_dir, tag):
         assert torch.equal(iou.cpu(), torch.tensor([4 / 7])) and torch.equal(ioum.cpu(), torch.tensor([2 / 3]))
 
 
-@pytest.mark.parametrize("B,P,hi", [(32, 196, 60000), (8, 4096, 5000), (5, 1, 3), (4, 1024, 1 << 30), (2, 16383, 100)])
+# P <= 2047: keys counted in an LDS hash table; above: bitonic sort (both forms, and the boundary between them)
+@pytest.mark.parametrize("B,P,hi", [(32, 196, 60000), (8, 4096, 5000), (5, 1, 3), (4, 1024, 1 << 30), (2, 16383, 100),
+                                    (3, 2047, 900), (3, 2048, 900), (6, 196, 4)])
 def test_corr_iou_random_vs_oracle(B, P, hi):
     gen = torch.Generator().manual_seed(P)
     a = torch.randint(0, hi, (B, P), generator=gen)
