@@ -402,24 +402,16 @@ __global__ __launch_bounds__(QT3) void quantile_select_kernel(QuantJobs jobs) {
 // on narrow-band rows -- 70 us instead of 63-66: the passes are bound by their ~30 VALU instructions per element on the
 // one CU a row has, not by atomic conflicts.)
 constexpr int QROW_MAX = CP2_QUANTILES_ROW_MAX;
-__global__ __launch_bounds__(QT3) void quantiles_row_kernel(QuantJobs jobs) {
-    int jsel = 0;
-#pragma unroll
-    for (int j = 1; j < QJOBS; ++j) jsel += ((int)blockIdx.x >= jobs.first_row[j]) ? 1 : 0;
-    const QuantArgs& a = jobs.job[jsel];
-    extern __shared__ __attribute__((aligned(16))) unsigned char q_smem[];
+// The three-level select of one row by one 1024-thread workgroup (the body of quantiles_row_kernel; also the fall-back of
+// quantiles_sample_kernel).  lma / lmb: the row's masks in LDS (loaded by the caller when the job is masked).
+__device__ __forceinline__ void row_three_pass(const QuantArgs& a, const int r, float* lma, float* lmb) {
     __shared__ unsigned hist0[QB0];
     __shared__ unsigned hist[QMAX][QB1];
     __shared__ unsigned wtot[16];
     __shared__ unsigned sh_prefix[QMAX], sh_k[QMAX], sh_min[QMAX], sh_next[QMAX], sh_n;
-    float* lma = reinterpret_cast<float*>(q_smem);
-    float* lmb = lma + (a.want >= 0 ? a.P : 0);
-    const int r = (int)blockIdx.x - jobs.first_row[jsel], tid = threadIdx.x, NQ = a.NQ;
+    const int tid = threadIdx.x, NQ = a.NQ;
     const float* row = a.x + (int64_t)r * a.s_row;
     const bool masked = a.want >= 0;
-    if (masked) {
-        for (int i = tid; i < a.P; i += QT3) { lma[i] = a.mask_a[(int64_t)r * a.P + i]; lmb[i] = a.mask_b[(int64_t)r * a.P + i]; }
-    }
     for (int i = tid; i < QB0; i += QT3) hist0[i] = 0;
     __syncthreads();
     const bool vec = a.s_elem == 1 && ((reinterpret_cast<uintptr_t>(row) & 15u) == 0);
@@ -572,6 +564,21 @@ __global__ __launch_bounds__(QT3) void quantiles_row_kernel(QuantJobs jobs) {
         a.out[(int64_t)j * a.R + r] = (w < 0.5f) ? v_lo + w * d : v_hi - d * (1.f - w);
     }
 #undef CP2_Q_FOREACH
+}
+
+__global__ __launch_bounds__(QT3) void quantiles_row_kernel(QuantJobs jobs) {
+    int jsel = 0;
+#pragma unroll
+    for (int j = 1; j < QJOBS; ++j) jsel += ((int)blockIdx.x >= jobs.first_row[j]) ? 1 : 0;
+    const QuantArgs& a = jobs.job[jsel];
+    extern __shared__ __attribute__((aligned(16))) unsigned char q_smem[];
+    float* lma = reinterpret_cast<float*>(q_smem);
+    float* lmb = lma + (a.want >= 0 ? a.P : 0);
+    const int r = (int)blockIdx.x - jobs.first_row[jsel];
+    if (a.want >= 0) {
+        for (int i = threadIdx.x; i < a.P; i += QT3) { lma[i] = a.mask_a[(int64_t)r * a.P + i]; lmb[i] = a.mask_b[(int64_t)r * a.P + i]; }
+    }
+    row_three_pass(a, r, lma, lmb);
 }
 
 // ---- rows of at most QROW_MAX elements, a few hundred chunks in total (the training step: 576): ONE launch, one
@@ -784,6 +791,259 @@ __global__ __launch_bounds__(QT1, 3) void quantiles_coop_kernel(QuantJobs jobs) 
     if (tid == 0 && atomicAdd(&sel[1], 1u) == (unsigned)G - 1u) { atomicExch(&sel[0], 0u); atomicExch(&sel[1], 0u); }
 }
 
+// ---- rows of at most QROW_MAX elements, round 3: ONE pass over the row instead of three.
+// A workgroup per row, as quantiles_row_kernel, but the bulk of the row is only CLASSIFIED:
+//   S  one sample per thread (stride N / 1024); every thread ranks its sample among all of them by counting (1024 LDS
+//      reads), and for each quantile q the samples of rank q (s-1) -+ 4 sqrt(q (1-q) s) become a bracket [lo, hi] in key
+//      space: it holds the wanted order statistic with probability 1 - 6e-5, whatever the distribution (narrow bands and
+//      rows of a few distinct values included: the bracket is made of values of the row itself);
+//   B  the one pass: per quantile count the keys below the bracket, keep the smallest key above it, and collect the keys
+//      inside it in LDS (about 9 % of the row; 24576 slots for all quantiles of the row); the row sum rides along;
+//   C  the wanted rank, now known exactly (n is the count of kept elements), must fall inside the collected keys;
+//      the keys at that position and the next one are found by a 4 x 8-bit radix select over the collected keys of
+//      all quantiles at once (the next position may be the smallest key above the bracket).
+// If a bracket misses (rank outside, more keys than slots, fewer than 64 samples kept) the row is redone by the three-pass
+// select above: same result, three passes.  Exact order statistics by integer counting, as before: bit-equal to
+// torch.nanquantile in the same tests.
+constexpr int QCAND = 24576;
+constexpr int QSAMP = QT3;
+
+template <typename F>
+__device__ __forceinline__ void row_visit(const QuantArgs& a, const float* row, const float* lma, const float* lmb, F&& f) {
+    const int tid = threadIdx.x;
+    const bool masked = a.want >= 0, wantpos = a.want != 0;
+    const bool vec = a.s_elem == 1 && ((reinterpret_cast<uintptr_t>(row) & 15u) == 0);
+    if (vec) {
+        const int n4 = (a.N + 3) >> 2;
+        for (int j4 = tid; j4 < n4; j4 += 4 * QT3) {
+            float4 t4[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {                  // four 16-byte loads in flight
+                const int i0 = (j4 + g * QT3) * 4;
+                if (i0 + 3 < a.N) {
+                    t4[g] = *reinterpret_cast<const float4*>(row + i0);
+                } else {
+                    t4[g].x = (i0 + 0 < a.N) ? row[i0 + 0] : NAN;
+                    t4[g].y = (i0 + 1 < a.N) ? row[i0 + 1] : NAN;
+                    t4[g].z = (i0 + 2 < a.N) ? row[i0 + 2] : NAN;
+                    t4[g].w = NAN;
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int i0 = (j4 + g * QT3) * 4;
+                const float vv[4] = {t4[g].x, t4[g].y, t4[g].z, t4[g].w};
+                int x_ = masked ? i0 / a.P : 0, y_ = masked ? i0 % a.P : 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float v = vv[u];
+                    bool keep = v == v;                    // nanquantile ignores NaN (also the padding above)
+                    if (keep && masked) keep = ((lma[x_] * lmb[y_]) != 0.f) == wantpos;
+                    if (keep) f(v);
+                    if (masked && ++y_ >= a.P) { y_ = 0; ++x_; }
+                }
+            }
+        }
+    } else {
+        for (int i0 = tid; i0 < a.N; i0 += 4 * QT3) {
+            float vv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * QT3;
+                vv[u] = i < a.N ? row[(int64_t)i * a.s_elem] : NAN;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * QT3;
+                const float v = vv[u];
+                bool keep = v == v;
+                if (keep && masked) keep = ((lma[i / a.P] * lmb[i % a.P]) != 0.f) == wantpos;
+                if (keep) f(v);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(QT3) void quantiles_sample_kernel(QuantJobs jobs) {
+    int jsel = 0;
+#pragma unroll
+    for (int j = 1; j < QJOBS; ++j) jsel += ((int)blockIdx.x >= jobs.first_row[j]) ? 1 : 0;
+    const QuantArgs& a = jobs.job[jsel];
+    extern __shared__ __attribute__((aligned(16))) unsigned char q_smem[];
+    const int r = (int)blockIdx.x - jobs.first_row[jsel], tid = threadIdx.x, NQ = a.NQ, N = a.N;
+    const bool masked = a.want >= 0;
+    float* lma = reinterpret_cast<float*>(q_smem);
+    float* lmb = lma + (masked ? a.P : 0);
+    unsigned* cand = reinterpret_cast<unsigned*>(lma + (masked ? ((2 * a.P + 3) & ~3) : 0));      // [NQ][CAP]
+    unsigned* skey = cand + QCAND;                                                                // [QSAMP]
+    __shared__ unsigned s_cnt[QMAX], s_below[QMAX], s_above[QMAX], s_lo[QMAX], s_hi[QMAX], s_n, s_fail;
+    __shared__ unsigned hsel[2 * QMAX][256];
+    __shared__ unsigned t_prefix[2 * QMAX], t_rank[2 * QMAX];
+    __shared__ double sum_w[QT3 / 64];
+    const float* row = a.x + (int64_t)r * a.s_row;
+    if (masked) {
+        for (int i = tid; i < a.P; i += QT3) { lma[i] = a.mask_a[(int64_t)r * a.P + i]; lmb[i] = a.mask_b[(int64_t)r * a.P + i]; }
+    }
+    if (tid < QMAX) { s_cnt[tid] = 0; s_below[tid] = 0; s_above[tid] = QNONE; s_lo[tid] = 0; s_hi[tid] = QNONE; }
+    if (tid == 0) { s_n = 0; s_fail = 0; }
+    __syncthreads();
+    const int CAP = QCAND / NQ;
+    // ------------------------------------------------------------------------------------------------ S: sample and brackets
+    {
+        const int stride = (N + QSAMP - 1) / QSAMP;
+        const int i = tid * stride + (stride >> 1);
+        unsigned key = QNONE;                              // not a sample: sorts behind every real key
+        if (i < N) {
+            const float v = row[(int64_t)i * a.s_elem];
+            bool keep = v == v;
+            if (keep && masked) keep = ((lma[i / a.P] * lmb[i % a.P]) != 0.f) == (a.want != 0);
+            if (keep) key = f2key(v);
+        }
+        skey[tid] = key;
+        const int sn = __syncthreads_count(key != QNONE);  // (also the barrier after the store)
+        int rank = 0;
+        for (int j = 0; j < QSAMP; ++j) {
+            const unsigned k2 = skey[j];
+            rank += (k2 < key || (k2 == key && j < tid)) ? 1 : 0;
+        }
+        if (sn < 64) {
+            if (tid == 0) s_fail = 1;
+        } else {
+            for (int j = 0; j < NQ; ++j) {
+                const float qj = a.q[j];
+                const float rho = qj * (float)(sn - 1), m = 4.f * sqrtf(fmaxf(qj * (1.f - qj), 0.f) * (float)sn) + 2.f;
+                const int lo_r = (int)floorf(rho - m), hi_r = (int)ceilf(rho + m);
+                if (key != QNONE && rank == lo_r) s_lo[j] = key;      // lo_r < 0: stays 0 (below every key)
+                if (key != QNONE && rank == hi_r) s_hi[j] = key;      // hi_r >= sn: stays QNONE (above every key)
+            }
+        }
+    }
+    __syncthreads();
+    if (s_fail) { row_three_pass(a, r, lma, lmb); return; }
+    // ------------------------------------------------------------------------------------------------ B: the one pass
+    unsigned lo[QMAX], hi[QMAX], below[QMAX], amin[QMAX];
+#pragma unroll
+    for (int j = 0; j < QMAX; ++j) { lo[j] = j < NQ ? s_lo[j] : 0u; hi[j] = j < NQ ? s_hi[j] : QNONE; below[j] = 0; amin[j] = QNONE; }
+    unsigned nkept = 0;
+    float lsum = 0.f;
+    row_visit(a, row, lma, lmb, [&](float v) {
+        const unsigned k = f2key(v);
+        ++nkept;
+        lsum += v;
+#pragma unroll
+        for (int j = 0; j < QMAX; ++j) {
+            if (j < NQ) {
+                if (k < lo[j]) ++below[j];
+                else if (k <= hi[j]) {
+                    const unsigned idx = atomicAdd(&s_cnt[j], 1u);
+                    if (idx < (unsigned)CAP) cand[j * CAP + idx] = k;
+                } else amin[j] = min(amin[j], k);
+            }
+        }
+    });
+    {
+        unsigned nk = nkept;
+        double ds = (double)lsum;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            nk += (unsigned)__shfl_xor((int)nk, off, 64);
+            ds += __shfl_xor(ds, off, 64);
+        }
+        if ((tid & 63) == 0) { atomicAdd(&s_n, nk); sum_w[tid >> 6] = ds; }
+#pragma unroll
+        for (int j = 0; j < QMAX; ++j) {
+            if (j < NQ) {
+                unsigned b = below[j], m = amin[j];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    b += (unsigned)__shfl_xor((int)b, off, 64);
+                    m = min(m, (unsigned)__shfl_xor((int)m, off, 64));
+                }
+                if ((tid & 63) == 0) { atomicAdd(&s_below[j], b); if (m != QNONE) atomicMin(&s_above[j], m); }
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned n = s_n;
+    if (n == 0) {
+        if (tid < NQ) a.out[(int64_t)tid * a.R + r] = NAN;
+        if (a.mean_out && tid == 0) a.mean_out[r] = NAN;
+        return;
+    }
+    // ------------------------------------------------------------------------------------------------ C: ranks inside the brackets
+    if (tid < NQ) {
+        const int j = tid;
+        const float rank = a.q[j] * (float)(n - 1);
+        const unsigned L = (unsigned)floorf(rank), cnt = s_cnt[j], bl = s_below[j];
+        if (cnt > (unsigned)CAP || L < bl || L - bl >= cnt) {
+            atomicExch(&s_fail, 1u);
+        } else {
+            const unsigned pL = L - bl;
+            t_rank[2 * j] = pL;
+            t_rank[2 * j + 1] = min(pL + 1, cnt - 1);
+            t_prefix[2 * j] = 0, t_prefix[2 * j + 1] = 0;
+        }
+    }
+    __syncthreads();
+    if (s_fail) { row_three_pass(a, r, lma, lmb); return; }
+    for (int level = 0; level < 4; ++level) {
+        const int shift = 24 - 8 * level;
+        for (int i = tid; i < 2 * QMAX * 256; i += QT3) (&hsel[0][0])[i] = 0;
+        __syncthreads();
+        for (int j = 0; j < NQ; ++j) {
+            const unsigned cnt = s_cnt[j];
+            const unsigned p0 = t_prefix[2 * j], p1 = t_prefix[2 * j + 1];
+            for (unsigned i = tid; i < cnt; i += QT3) {
+                const unsigned k = cand[j * CAP + i];
+                const unsigned top = level == 0 ? 0u : (k >> (shift + 8));
+                const unsigned bin = (k >> shift) & 255u;
+                if (top == p0) atomicAdd(&hsel[2 * j][bin], 1u);
+                if (top == p1) atomicAdd(&hsel[2 * j + 1][bin], 1u);
+            }
+        }
+        __syncthreads();
+        // one wave per target: locate the bin that holds the target's remaining rank (4 bins per lane, inclusive wave scan)
+        const int t = tid >> 6, lane = tid & 63;
+        if (t < 2 * NQ) {
+            const unsigned h0 = hsel[t][4 * lane], h1 = hsel[t][4 * lane + 1], h2 = hsel[t][4 * lane + 2], h3 = hsel[t][4 * lane + 3];
+            const unsigned tot = h0 + h1 + h2 + h3;
+            unsigned incl = tot;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned up = (unsigned)__shfl_up((int)incl, off, 64);
+                if (lane >= off) incl += up;
+            }
+            const unsigned excl = incl - tot, want = t_rank[t];
+            if (want >= excl && want < incl) {
+                unsigned kk = want - excl, b = 4 * lane;
+                if (kk >= h0) { kk -= h0; ++b; if (kk >= h1) { kk -= h1; ++b; if (kk >= h2) { kk -= h2; ++b; } } }
+                t_prefix[t] = (t_prefix[t] << 8) | b;
+                t_rank[t] = kk;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < NQ) {
+        const int j = tid;
+        const float rank = a.q[j] * (float)(n - 1);
+        const float lo_f = floorf(rank), w = rank - lo_f;
+        const unsigned pL = (unsigned)lo_f - s_below[j];
+        const float v_lo = key2f(t_prefix[2 * j]);
+        float v_hi = v_lo;
+        if (w != 0.f) {
+            if (pL + 1 < s_cnt[j]) v_hi = key2f(t_prefix[2 * j + 1]);
+            else if (s_above[j] != QNONE) v_hi = key2f(s_above[j]);
+        }
+        const float d = v_hi - v_lo;                         // at::lerp: w < 0.5 ? a + w*(b-a) : b - (b-a)*(1-w)
+        a.out[(int64_t)j * a.R + r] = (w < 0.5f) ? v_lo + w * d : v_hi - d * (1.f - w);
+    }
+    if (a.mean_out && tid == 0) {
+        double t = 0;
+        for (int i = 0; i < QT3 / 64; ++i) t += sum_w[i];
+        a.mean_out[r] = (n == (unsigned)N) ? (float)(t / (double)N) : NAN;   // a NaN element makes torch's mean NaN
+    }
+}
+
 static int quant_check(const QuantArgs& a) {
     if (!a.x || !a.q || !a.out) return CP2_ERR_NULL;
     if (a.R <= 0 || a.N <= 0 || a.NQ <= 0) return CP2_ERR_SHAPE;
@@ -806,12 +1066,16 @@ CP2_API int64_t cp2_quantiles_workspace_bytes(int njobs, const int* R, const int
     return 4 * quant_ws_words(njobs, R, N, NQ);
 }
 
-static int quant_launch(QuantJobs& jobs, int njobs, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+// form: 0 = automatic, 1 = three-pass row kernel, 2 = cooperative chunks (needs the workspace), see cp2hip.h
+static int quant_launch(QuantJobs& jobs, int njobs, int form, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
     bool small = true;
     for (int j = 0; j < njobs; ++j) small = small && jobs.job[j].N <= QROW_MAX;
     int64_t coop_wgs = 0;
     for (int j = 0; j < njobs; ++j) coop_wgs += (int64_t)jobs.job[j].R * cp2_cdiv(jobs.job[j].N > 0 ? jobs.job[j].N : 1, QCHUNK);
-    if (small && workspace && coop_wgs <= QCOOP_MAX_WGS) { // one launch, one workgroup per chunk, row-local barriers
+    if (form < 0 || form > 2) return CP2_ERR_SHAPE;
+    if (form != 0 && !small) return CP2_ERR_UNSUPPORTED;
+    if (form == 2 && (!workspace || coop_wgs > QCOOP_MAX_WGS)) return CP2_ERR_UNSUPPORTED;
+    if (form == 2) {                                       // one launch, one workgroup per chunk, row-local barriers
         if (!cp2_aligned16(workspace)) return CP2_ERR_ALIGN;
         int rows = 0, chunks = 0;
         int Rs[QJOBS], Ns[QJOBS];
@@ -850,6 +1114,17 @@ static int quant_launch(QuantJobs& jobs, int njobs, void* workspace, int64_t wor
             rows += jobs.job[j].R;
         }
         for (int j = njobs; j <= QJOBS; ++j) jobs.first_row[j] = rows;
+        if (form == 0) {                                   // default: one classifying pass per row (three-pass select as fall-back)
+            const size_t lds2 = ((lds + 15) & ~(size_t)15) + (size_t)(QCAND + QSAMP) * sizeof(unsigned);
+            constexpr int kMaxDyn = 110 * 1024;              // + ~41 KB of static LDS (the fall-back's histograms): under the 160 KB of a CU
+            if (lds2 <= (size_t)kMaxDyn) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(quantiles_sample_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDyn);
+                if (e != hipSuccess) return (int)e;
+                CP2_LAUNCH_PROFILED(quantiles_sample_kernel, dim3(rows), dim3(QT3), lds2, stream, jobs);
+                return cp2_launch_status();
+            }
+        }
         CP2_LAUNCH_PROFILED(quantiles_row_kernel, dim3(rows), dim3(QT3), lds, stream, jobs);
         return cp2_launch_status();
     }
@@ -896,18 +1171,19 @@ CP2_API int cp2_masked_quantiles(const float* x, int64_t stride_row, int64_t str
                                  float* out, void* workspace, int64_t workspace_bytes, void* stream) {
     QuantJobs jobs{};
     jobs.job[0] = QuantArgs{x, stride_row, stride_elem, N, mask_a, mask_b, P, want, q, NQ, out, R, 0, nullptr};
-    return quant_launch(jobs, 1, workspace, workspace_bytes, cp2_stream(stream));
+    return quant_launch(jobs, 1, 0, workspace, workspace_bytes, cp2_stream(stream));
 }
 
 CP2_API int cp2_masked_quantiles_multi(int njobs, const float* const* x, const int64_t* stride_row, const int64_t* stride_elem,
                                        const int* R, const int* N, const float* const* mask_a, const float* const* mask_b,
                                        const int* P, const int* want, const float* q, int NQ, float* const* out,
-                                       float* const* mean_out, void* workspace, int64_t workspace_bytes, void* stream) {
+                                       float* const* mean_out, int form, void* workspace, int64_t workspace_bytes, void* stream) {
     if (njobs <= 0 || njobs > QJOBS) return CP2_ERR_UNSUPPORTED;
     if (!x || !stride_row || !stride_elem || !R || !N || !mask_a || !mask_b || !P || !want || !out) return CP2_ERR_NULL;
     QuantJobs jobs{};
     for (int j = 0; j < njobs; ++j)
         jobs.job[j] = QuantArgs{x[j], stride_row[j], stride_elem[j], N[j], mask_a[j], mask_b[j], P[j], want[j], q, NQ, out[j], R[j], 0,
                                 mean_out ? mean_out[j] : nullptr};
-    return quant_launch(jobs, njobs, workspace, workspace_bytes, cp2_stream(stream));
+    return quant_launch(jobs, njobs, form, workspace, workspace_bytes, cp2_stream(stream));
 }
+

@@ -715,9 +715,9 @@ def _quartile_tensor(device) -> torch.Tensor:
 _QUANT_WS = {}
 QUANTILES_ROW_MAX = 131072     # CP2_QUANTILES_ROW_MAX
 QUANTILES_CHUNK = 8192         # QCHUNK in csrc/quantile.hip
-QUANTILES_COOP = False         # one workgroup per chunk with row-local barriers: measured 59.6 us vs 63.3 us for the
-                               # workgroup-per-row kernel at the step's shapes -- not worth a spin-wait in the product path; kept
-                               # for tools/bench_quantiles.py and the parity tests
+QUANTILES_FORM = 0             # one-launch form for rows up to QUANTILES_ROW_MAX: 0 = one classifying pass per row (sample
+                               # brackets; the product path), 1 = three-pass row kernel (round 2), 2 = cooperative chunks with
+                               # row-local barriers (58.9 us against 63.2 us for form 1; needs a workspace).  Identical results.
 QUANTILES_COOP_MAX_WGS = 768   # QCOOP_MAX_WGS: up to this many chunk workgroups the one-launch cooperative form is taken
 
 
@@ -774,8 +774,10 @@ def masked_quantiles_multi(jobs, q: Optional[torch.Tensor] = None):
     # barriers when the call is small enough for every chunk to be resident (the training step), else one workgroup per
     # row and no workspace (DenseCL's thousands of rows); longer rows: the chunked six-launch path
     small = all(j["N"] <= QUANTILES_ROW_MAX for j in jobs)
-    coop = small and QUANTILES_COOP and sum(j["R"] * -(-j["N"] // QUANTILES_CHUNK) for j in jobs) <= QUANTILES_COOP_MAX_WGS
-    ws = None if (small and not coop) else \
+    form = QUANTILES_FORM if small else 0
+    if form == 2 and sum(j["R"] * -(-j["N"] // QUANTILES_CHUNK) for j in jobs) > QUANTILES_COOP_MAX_WGS:
+        form = 0                                          # too many chunks to be resident at once
+    ws = None if (small and form != 2) else \
         _quant_workspace(dev, [j["R"] for j in jobs], [j["N"] for j in jobs], q.numel())
     _profile("quantiles")
     rc = lib.cp2_masked_quantiles_multi(
@@ -783,7 +785,7 @@ def masked_quantiles_multi(jobs, q: Optional[torch.Tensor] = None):
         I32(*[j["R"] for j in jobs]), I32(*[j["N"] for j in jobs]), P_(*ma), P_(*mb),
         I32(*[(j["mask_a"].shape[1] if j.get("mask_a") is not None else 0) for j in jobs]),
         I32(*[j.get("want", -1) for j in jobs]), _dev(q, "q", torch.float32), q.numel(), P_(*[o.data_ptr() for o in outs]),
-        P_(*means) if any(m is not None for m in means) else None,
+        P_(*means) if any(m is not None for m in means) else None, form,
         None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel() * 4, _stream())
     if rc and ws is not None:
         ws.zero_()                                        # a failed call may have left counts behind

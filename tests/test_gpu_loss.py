@@ -313,14 +313,15 @@ def test_rowkey_large_split_property():
     grad_close(got.dE[:, 0], p_cpu.grad, "slice d pos")
 
 
-@pytest.mark.parametrize("coop", [False, True], ids=["row-kernel", "chunk-cooperative"])
-def test_masked_quantiles_bit_exact_vs_torch(coop):
+@pytest.mark.parametrize("form", [0, 1, 2], ids=["one-pass-brackets", "three-pass-row", "chunk-cooperative"])
+def test_masked_quantiles_bit_exact_vs_torch(form):
     """Same input -> the radix-select quantiles equal torch.quantile / torch.nanquantile bit for bit
-    (the reference's convention, tests/test_contrastive_metrics.py:50-57).  Both one-launch forms for rows up to 131072
-    elements: a workgroup per row (the product path) and a workgroup per chunk with row-local barriers (kept as an option:
-    6 % faster at the step's shapes), plus the row means torch's x.mean(1) gives."""
-    old = ops.QUANTILES_COOP
-    ops.QUANTILES_COOP = coop
+    (the reference's convention, tests/test_contrastive_metrics.py:50-57).  All three one-launch forms for rows up to
+    131072 elements: one classifying pass with sample brackets (the product path; rows whose bracket misses fall back to
+    the three-pass select inside the kernel), the three-pass row kernel, and a workgroup per chunk with row-local barriers
+    (DESIGN.md section 4), plus the row means torch's x.mean(1) gives."""
+    old = ops.QUANTILES_FORM
+    ops.QUANTILES_FORM = form
     try:
         _masked_quantiles_cases()
         gen = torch.Generator().manual_seed(8)
@@ -332,7 +333,7 @@ def test_masked_quantiles_bit_exact_vs_torch(coop):
         want = x.double().mean(1).float()
         assert torch.isnan(means[2]) and (means.cpu()[[0, 1, 3, 4, 5]] - want[[0, 1, 3, 4, 5]]).abs().max() <= 1e-6
     finally:
-        ops.QUANTILES_COOP = old
+        ops.QUANTILES_FORM = old
 
 
 def _masked_quantiles_cases():
