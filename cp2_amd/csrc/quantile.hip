@@ -864,147 +864,28 @@ __device__ __forceinline__ void row_visit(const QuantArgs& a, const float* row, 
     }
 }
 
-__global__ __launch_bounds__(QT3) void quantiles_sample_kernel(QuantJobs jobs) {
-    int jsel = 0;
-#pragma unroll
-    for (int j = 1; j < QJOBS; ++j) jsel += ((int)blockIdx.x >= jobs.first_row[j]) ? 1 : 0;
-    const QuantArgs& a = jobs.job[jsel];
-    extern __shared__ __attribute__((aligned(16))) unsigned char q_smem[];
-    const int r = (int)blockIdx.x - jobs.first_row[jsel], tid = threadIdx.x, NQ = a.NQ, N = a.N;
-    const bool masked = a.want >= 0;
-    float* lma = reinterpret_cast<float*>(q_smem);
-    float* lmb = lma + (masked ? a.P : 0);
-    unsigned* cand = reinterpret_cast<unsigned*>(lma + (masked ? ((2 * a.P + 3) & ~3) : 0));      // [NQ][CAP]
-    unsigned* skey = cand + QCAND;                                                                // [QSAMP]
-    __shared__ unsigned s_cnt[QMAX], s_below[QMAX], s_above[QMAX], s_lo[QMAX], s_hi[QMAX], s_n, s_fail;
-    __shared__ unsigned hsel[2 * QMAX][256];
-    __shared__ unsigned t_prefix[2 * QMAX], t_rank[2 * QMAX];
-    __shared__ double sum_w[QT3 / 64];
-    const float* row = a.x + (int64_t)r * a.s_row;
-    if (masked) {
-        for (int i = tid; i < a.P; i += QT3) { lma[i] = a.mask_a[(int64_t)r * a.P + i]; lmb[i] = a.mask_b[(int64_t)r * a.P + i]; }
-    }
-    if (tid < QMAX) { s_cnt[tid] = 0; s_below[tid] = 0; s_above[tid] = QNONE; s_lo[tid] = 0; s_hi[tid] = QNONE; }
-    if (tid == 0) { s_n = 0; s_fail = 0; }
-    __syncthreads();
-    const int CAP = QCAND / NQ;
-    // ------------------------------------------------------------------------------------------------ S: sample and brackets
-    {
-        const int stride = (N + QSAMP - 1) / QSAMP;
-        const int i = tid * stride + (stride >> 1);
-        unsigned key = QNONE;                              // not a sample: sorts behind every real key
-        if (i < N) {
-            const float v = row[(int64_t)i * a.s_elem];
-            bool keep = v == v;
-            if (keep && masked) keep = ((lma[i / a.P] * lmb[i % a.P]) != 0.f) == (a.want != 0);
-            if (keep) key = f2key(v);
-        }
-        skey[tid] = key;
-        const int sn = __syncthreads_count(key != QNONE);  // (also the barrier after the store)
-        int rank = 0;
-        for (int j = 0; j < QSAMP; ++j) {
-            const unsigned k2 = skey[j];
-            rank += (k2 < key || (k2 == key && j < tid)) ? 1 : 0;
-        }
-        if (sn < 64) {
-            if (tid == 0) s_fail = 1;
-        } else {
-            for (int j = 0; j < NQ; ++j) {
-                const float qj = a.q[j];
-                const float rho = qj * (float)(sn - 1), m = 4.f * sqrtf(fmaxf(qj * (1.f - qj), 0.f) * (float)sn) + 2.f;
-                const int lo_r = (int)floorf(rho - m), hi_r = (int)ceilf(rho + m);
-                if (key != QNONE && rank == lo_r) s_lo[j] = key;      // lo_r < 0: stays 0 (below every key)
-                if (key != QNONE && rank == hi_r) s_hi[j] = key;      // hi_r >= sn: stays QNONE (above every key)
-            }
-        }
-    }
-    __syncthreads();
-    if (s_fail) { row_three_pass(a, r, lma, lmb); return; }
-    // ------------------------------------------------------------------------------------------------ B: the one pass
-    unsigned lo[QMAX], hi[QMAX], below[QMAX], amin[QMAX];
-#pragma unroll
-    for (int j = 0; j < QMAX; ++j) { lo[j] = j < NQ ? s_lo[j] : 0u; hi[j] = j < NQ ? s_hi[j] : QNONE; below[j] = 0; amin[j] = QNONE; }
-    unsigned nkept = 0;
-    float lsum = 0.f;
-    row_visit(a, row, lma, lmb, [&](float v) {
-        const unsigned k = f2key(v);
-        ++nkept;
-        lsum += v;
-#pragma unroll
-        for (int j = 0; j < QMAX; ++j) {
-            if (j < NQ) {
-                if (k < lo[j]) ++below[j];
-                else if (k <= hi[j]) {
-                    const unsigned idx = atomicAdd(&s_cnt[j], 1u);
-                    if (idx < (unsigned)CAP) cand[j * CAP + idx] = k;
-                } else amin[j] = min(amin[j], k);
-            }
-        }
-    });
-    {
-        unsigned nk = nkept;
-        double ds = (double)lsum;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            nk += (unsigned)__shfl_xor((int)nk, off, 64);
-            ds += __shfl_xor(ds, off, 64);
-        }
-        if ((tid & 63) == 0) { atomicAdd(&s_n, nk); sum_w[tid >> 6] = ds; }
-#pragma unroll
-        for (int j = 0; j < QMAX; ++j) {
-            if (j < NQ) {
-                unsigned b = below[j], m = amin[j];
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    b += (unsigned)__shfl_xor((int)b, off, 64);
-                    m = min(m, (unsigned)__shfl_xor((int)m, off, 64));
-                }
-                if ((tid & 63) == 0) { atomicAdd(&s_below[j], b); if (m != QNONE) atomicMin(&s_above[j], m); }
-            }
-        }
-    }
-    __syncthreads();
-    const unsigned n = s_n;
-    if (n == 0) {
-        if (tid < NQ) a.out[(int64_t)tid * a.R + r] = NAN;
-        if (a.mean_out && tid == 0) a.mean_out[r] = NAN;
-        return;
-    }
-    // ------------------------------------------------------------------------------------------------ C: ranks inside the brackets
-    if (tid < NQ) {
-        const int j = tid;
-        const float rank = a.q[j] * (float)(n - 1);
-        const unsigned L = (unsigned)floorf(rank), cnt = s_cnt[j], bl = s_below[j];
-        if (cnt > (unsigned)CAP || L < bl || L - bl >= cnt) {
-            atomicExch(&s_fail, 1u);
-        } else {
-            const unsigned pL = L - bl;
-            t_rank[2 * j] = pL;
-            t_rank[2 * j + 1] = min(pL + 1, cnt - 1);
-            t_prefix[2 * j] = 0, t_prefix[2 * j + 1] = 0;
-        }
-    }
-    __syncthreads();
-    if (s_fail) { row_three_pass(a, r, lma, lmb); return; }
+// Keys at given ranks of key lists held in LDS, for up to 2 * QMAX targets at once: four levels of eight bits; target t
+// looks at list t_list[t] (keys at lists + t_list[t] * stride, counts[t_list[t]] of them) and wants the key of rank
+// t_rank[t] (0-based).  On return t_prefix[t] is that key.  One wave per target does the scan of a level.
+__device__ __forceinline__ void select_targets(const unsigned* lists, int stride, const unsigned* counts, const int* t_list, int nt,
+                                               unsigned (*hsel)[256], unsigned* t_prefix, unsigned* t_rank) {
+    const int tid = threadIdx.x;
     for (int level = 0; level < 4; ++level) {
         const int shift = 24 - 8 * level;
         for (int i = tid; i < 2 * QMAX * 256; i += QT3) (&hsel[0][0])[i] = 0;
         __syncthreads();
-        for (int j = 0; j < NQ; ++j) {
-            const unsigned cnt = s_cnt[j];
-            const unsigned p0 = t_prefix[2 * j], p1 = t_prefix[2 * j + 1];
+        for (int t = 0; t < nt; ++t) {
+            const int l = t_list[t];
+            const unsigned cnt = counts[l], pre = t_prefix[t];
+            const unsigned* keys = lists + l * stride;
             for (unsigned i = tid; i < cnt; i += QT3) {
-                const unsigned k = cand[j * CAP + i];
-                const unsigned top = level == 0 ? 0u : (k >> (shift + 8));
-                const unsigned bin = (k >> shift) & 255u;
-                if (top == p0) atomicAdd(&hsel[2 * j][bin], 1u);
-                if (top == p1) atomicAdd(&hsel[2 * j + 1][bin], 1u);
+                const unsigned k = keys[i];
+                if (level == 0 || (k >> (shift + 8)) == pre) atomicAdd(&hsel[t][(k >> shift) & 255u], 1u);
             }
         }
         __syncthreads();
-        // one wave per target: locate the bin that holds the target's remaining rank (4 bins per lane, inclusive wave scan)
         const int t = tid >> 6, lane = tid & 63;
-        if (t < 2 * NQ) {
+        if (t < nt) {
             const unsigned h0 = hsel[t][4 * lane], h1 = hsel[t][4 * lane + 1], h2 = hsel[t][4 * lane + 2], h3 = hsel[t][4 * lane + 3];
             const unsigned tot = h0 + h1 + h2 + h3;
             unsigned incl = tot;
@@ -1023,17 +904,183 @@ __global__ __launch_bounds__(QT3) void quantiles_sample_kernel(QuantJobs jobs) {
         }
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(QT3) void quantiles_sample_kernel(QuantJobs jobs) {
+    int jsel = 0;
+#pragma unroll
+    for (int j = 1; j < QJOBS; ++j) jsel += ((int)blockIdx.x >= jobs.first_row[j]) ? 1 : 0;
+    const QuantArgs& a = jobs.job[jsel];
+    extern __shared__ __attribute__((aligned(16))) unsigned char q_smem[];
+    const int r = (int)blockIdx.x - jobs.first_row[jsel], tid = threadIdx.x, NQ = a.NQ, N = a.N;
+    const bool masked = a.want >= 0;
+    float* lma = reinterpret_cast<float*>(q_smem);
+    float* lmb = lma + (masked ? a.P : 0);
+    unsigned* cand = reinterpret_cast<unsigned*>(lma + (masked ? ((2 * a.P + 3) & ~3) : 0));      // [NQ][CAP]
+    unsigned* skey = cand + QCAND;                                                                // [QSAMP]
+    __shared__ unsigned s_cnt[QMAX], s_below[QMAX], s_above[QMAX], s_lo[QMAX], s_hi[QMAX], s_eqlo[QMAX], s_eqhi[QMAX], s_n, s_fail;
+    __shared__ unsigned hsel[2 * QMAX][256];
+    __shared__ unsigned t_prefix[2 * QMAX], t_rank[2 * QMAX], t_kind[2 * QMAX], s_cntS;
+    __shared__ int t_list[2 * QMAX];
+    __shared__ double sum_w[QT3 / 64];
+    const float* row = a.x + (int64_t)r * a.s_row;
+    if (masked) {
+        for (int i = tid; i < a.P; i += QT3) { lma[i] = a.mask_a[(int64_t)r * a.P + i]; lmb[i] = a.mask_b[(int64_t)r * a.P + i]; }
+    }
+    if (tid < QMAX) { s_cnt[tid] = 0; s_below[tid] = 0; s_above[tid] = QNONE; s_lo[tid] = 0; s_hi[tid] = QNONE; s_eqlo[tid] = 0; s_eqhi[tid] = 0; }
+    if (tid == 0) { s_n = 0; s_fail = 0; }
+    __syncthreads();
+    const int CAP = QCAND / NQ;
+    // ------------------------------------------------------------------------------------------------ S: sample and brackets
+    {
+        const int stride = (N + QSAMP - 1) / QSAMP;
+        const int i = tid * stride + (stride >> 1);
+        unsigned key = QNONE;                              // not a sample: sorts behind every real key
+        if (i < N) {
+            const float v = row[(int64_t)i * a.s_elem];
+            bool keep = v == v;
+            if (keep && masked) keep = ((lma[i / a.P] * lmb[i % a.P]) != 0.f) == (a.want != 0);
+            if (keep) key = f2key(v);
+        }
+        skey[tid] = key;
+        const int sn = __syncthreads_count(key != QNONE);  // (also the barrier after the store)
+        if (sn < 64) {
+            if (tid == 0) s_fail = 1;
+        } else if (tid < 2 * NQ) {
+            // targets 2j / 2j+1: the samples of rank q (sn-1) -+ 4 sqrt(q (1-q) sn) (- 2 / + 2); a rank outside the sample
+            // leaves that end open.  The invalid slots of the sample hold QNONE and sort behind every real key.
+            const int j = tid >> 1, up = tid & 1;
+            const float qj = a.q[j];
+            const float rho = qj * (float)(sn - 1), m = 4.f * sqrtf(fmaxf(qj * (1.f - qj), 0.f) * (float)sn) + 2.f;
+            const int rk = up ? (int)ceilf(rho + m) : (int)floorf(rho - m);
+            t_list[tid] = 0;
+            t_prefix[tid] = 0;
+            t_kind[tid] = (rk < 0 || rk >= sn) ? 1u : 0u;   // 1: open end
+            t_rank[tid] = (unsigned)min(max(rk, 0), sn - 1);
+        }
+        if (tid == 0) s_cntS = QSAMP;
+    }
+    __syncthreads();
+    if (s_fail) { row_three_pass(a, r, lma, lmb); return; }
+    select_targets(skey, 0, &s_cntS, t_list, 2 * NQ, hsel, t_prefix, t_rank);
+    if (tid < 2 * NQ) {
+        const int j = tid >> 1;
+        if (tid & 1) s_hi[j] = t_kind[tid] ? QNONE : t_prefix[tid];
+        else s_lo[j] = t_kind[tid] ? 0u : t_prefix[tid];
+    }
+    __syncthreads();
+    if (s_fail) { row_three_pass(a, r, lma, lmb); return; }
+    // ------------------------------------------------------------------------------------------------ B: the one pass
+    // keys EQUAL to a bracket end are counted, not stored: a row of a few distinct values (the dense logits of a freshly
+    // initialised encoder) has brackets whose ends are those values, and nothing strictly inside
+    unsigned lo[QMAX], hi[QMAX], below[QMAX], amin[QMAX], eqlo[QMAX], eqhi[QMAX];
+#pragma unroll
+    for (int j = 0; j < QMAX; ++j) {
+        lo[j] = j < NQ ? s_lo[j] : 0u; hi[j] = j < NQ ? s_hi[j] : QNONE;
+        below[j] = 0; amin[j] = QNONE; eqlo[j] = 0; eqhi[j] = 0;
+    }
+    unsigned nkept = 0;
+    float lsum = 0.f;
+    row_visit(a, row, lma, lmb, [&](float v) {
+        const unsigned k = f2key(v);
+        ++nkept;
+        lsum += v;
+#pragma unroll
+        for (int j = 0; j < QMAX; ++j) {
+            if (j < NQ) {
+                if (k < lo[j]) ++below[j];
+                else if (k == lo[j]) ++eqlo[j];
+                else if (k == hi[j]) ++eqhi[j];
+                else if (k > hi[j]) amin[j] = min(amin[j], k);
+                // strictly inside: one LDS atomic per wave and quantile reserves the slots of all its lanes
+                const bool in = k > lo[j] && k < hi[j];
+                const unsigned long long mk = __ballot(in);
+                if (mk) {
+                    const int lane = tid & 63, leader = __ffsll((long long)mk) - 1;
+                    unsigned base = 0;
+                    if (lane == leader) base = atomicAdd(&s_cnt[j], (unsigned)__popcll(mk));
+                    base = (unsigned)__shfl((int)base, leader, 64);
+                    const unsigned idx = base + (unsigned)__popcll(mk & ((1ull << lane) - 1ull));
+                    if (in && idx < (unsigned)CAP) cand[j * CAP + idx] = k;
+                }
+            }
+        }
+    });
+    {
+        unsigned nk = nkept;
+        double ds = (double)lsum;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            nk += (unsigned)__shfl_xor((int)nk, off, 64);
+            ds += __shfl_xor(ds, off, 64);
+        }
+        if ((tid & 63) == 0) { atomicAdd(&s_n, nk); sum_w[tid >> 6] = ds; }
+#pragma unroll
+        for (int j = 0; j < QMAX; ++j) {
+            if (j < NQ) {
+                unsigned b = below[j], m = amin[j], el = eqlo[j], eh = eqhi[j];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    b += (unsigned)__shfl_xor((int)b, off, 64);
+                    el += (unsigned)__shfl_xor((int)el, off, 64);
+                    eh += (unsigned)__shfl_xor((int)eh, off, 64);
+                    m = min(m, (unsigned)__shfl_xor((int)m, off, 64));
+                }
+                if ((tid & 63) == 0) {
+                    atomicAdd(&s_below[j], b); atomicAdd(&s_eqlo[j], el); atomicAdd(&s_eqhi[j], eh);
+                    if (m != QNONE) atomicMin(&s_above[j], m);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned n = s_n;
+    if (n == 0) {
+        if (tid < NQ) a.out[(int64_t)tid * a.R + r] = NAN;
+        if (a.mean_out && tid == 0) a.mean_out[r] = NAN;
+        return;
+    }
+    // ------------------------------------------------------------------------------------------------ C: ranks inside the brackets
+    // sorted content of bracket j: [eqlo copies of lo][the cnt stored keys, strictly inside][eqhi copies of hi], then the keys
+    // above it.  Positions L - below and L - below + 1 are each: 0 = lo, 1 = a stored key (radix select), 2 = hi, 3 = above.
+    if (tid < NQ) {
+        const int j = tid;
+        const float rank = a.q[j] * (float)(n - 1);
+        const unsigned L = (unsigned)floorf(rank), cnt = s_cnt[j], bl = s_below[j], el = s_eqlo[j], eh = s_eqhi[j];
+        if (cnt > (unsigned)CAP || L < bl || L - bl >= el + cnt + eh) {
+            atomicExch(&s_fail, 1u);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const unsigned pos = L - bl + u;
+                unsigned kind, rk = 0;
+                if (pos < el) kind = 0;
+                else if (pos < el + cnt) { kind = 1; rk = pos - el; }
+                else if (pos < el + cnt + eh) kind = 2;
+                else kind = 3;
+                t_kind[2 * j + u] = kind;
+                t_rank[2 * j + u] = rk;
+                t_prefix[2 * j + u] = 0;
+                t_list[2 * j + u] = j;
+            }
+        }
+    }
+    __syncthreads();
+    if (s_fail) { row_three_pass(a, r, lma, lmb); return; }
+    select_targets(cand, CAP, s_cnt, t_list, 2 * NQ, hsel, t_prefix, t_rank);
     if (tid < NQ) {
         const int j = tid;
         const float rank = a.q[j] * (float)(n - 1);
         const float lo_f = floorf(rank), w = rank - lo_f;
-        const unsigned pL = (unsigned)lo_f - s_below[j];
-        const float v_lo = key2f(t_prefix[2 * j]);
-        float v_hi = v_lo;
-        if (w != 0.f) {
-            if (pL + 1 < s_cnt[j]) v_hi = key2f(t_prefix[2 * j + 1]);
-            else if (s_above[j] != QNONE) v_hi = key2f(s_above[j]);
-        }
+        auto value = [&](int t, float dflt) -> float {
+            const unsigned kind = t_kind[t];
+            if (kind == 0) return key2f(s_lo[j]);
+            if (kind == 1) return key2f(t_prefix[t]);
+            if (kind == 2) return key2f(s_hi[j]);
+            return s_above[j] != QNONE ? key2f(s_above[j]) : dflt;
+        };
+        const float v_lo = value(2 * j, 0.f);
+        const float v_hi = w != 0.f ? value(2 * j + 1, v_lo) : v_lo;
         const float d = v_hi - v_lo;                         // at::lerp: w < 0.5 ? a + w*(b-a) : b - (b-a)*(1-w)
         a.out[(int64_t)j * a.R + r] = (w < 0.5f) ? v_lo + w * d : v_hi - d * (1.f - w);
     }
