@@ -404,9 +404,8 @@ __global__ __launch_bounds__(QT3) void quantile_select_kernel(QuantJobs jobs) {
 constexpr int QROW_MAX = CP2_QUANTILES_ROW_MAX;
 // The three-level select of one row by one 1024-thread workgroup (the body of quantiles_row_kernel; also the fall-back of
 // quantiles_sample_kernel).  lma / lmb: the row's masks in LDS (loaded by the caller when the job is masked).
-__device__ __forceinline__ void row_three_pass(const QuantArgs& a, const int r, float* lma, float* lmb) {
-    __shared__ unsigned hist0[QB0];
-    __shared__ unsigned hist[QMAX][QB1];
+__device__ __forceinline__ void row_three_pass(const QuantArgs& a, const int r, float* lma, float* lmb, unsigned* hist0,
+                                               unsigned (*hist)[QB1]) {
     __shared__ unsigned wtot[16];
     __shared__ unsigned sh_prefix[QMAX], sh_k[QMAX], sh_min[QMAX], sh_next[QMAX], sh_n;
     const int tid = threadIdx.x, NQ = a.NQ;
@@ -578,7 +577,9 @@ __global__ __launch_bounds__(QT3) void quantiles_row_kernel(QuantJobs jobs) {
     if (a.want >= 0) {
         for (int i = threadIdx.x; i < a.P; i += QT3) { lma[i] = a.mask_a[(int64_t)r * a.P + i]; lmb[i] = a.mask_b[(int64_t)r * a.P + i]; }
     }
-    row_three_pass(a, r, lma, lmb);
+    __shared__ unsigned hist0[QB0];
+    __shared__ unsigned hist[QMAX][QB1];
+    row_three_pass(a, r, lma, lmb, hist0, hist);
 }
 
 // ---- rows of at most QROW_MAX elements, a few hundred chunks in total (the training step: 576): ONE launch, one
@@ -793,20 +794,20 @@ __global__ __launch_bounds__(QT1, 3) void quantiles_coop_kernel(QuantJobs jobs) 
 
 // ---- rows of at most QROW_MAX elements, round 3: ONE pass over the row instead of three.
 // A workgroup per row, as quantiles_row_kernel, but the bulk of the row is only CLASSIFIED:
-//   S  one sample per thread (stride N / 1024); every thread ranks its sample among all of them by counting (1024 LDS
-//      reads), and for each quantile q the samples of rank q (s-1) -+ 4 sqrt(q (1-q) s) become a bracket [lo, hi] in key
-//      space: it holds the wanted order statistic with probability 1 - 6e-5, whatever the distribution (narrow bands and
+//   S  4096 samples of the row (stride N / 4096); for each quantile q the samples of rank q (s-1) -+ 4 sqrt(q (1-q) s), found
+//      by a radix select over the samples, become a bracket [lo, hi] in key space (about 8 n / sqrt(s) = n / 8 ... n / 16 keys): it holds the wanted order statistic with probability 1 - 6e-5, whatever the distribution (narrow bands and
 //      rows of a few distinct values included: the bracket is made of values of the row itself);
 //   B  the one pass: per quantile count the keys below the bracket, keep the smallest key above it, and collect the keys
-//      inside it in LDS (about 9 % of the row; 24576 slots for all quantiles of the row); the row sum rides along;
+//      strictly inside it in LDS (30720 slots for all quantiles of the row; keys equal to a bracket end are counted, so a
+//      row of a few distinct values stores nothing); the row sum rides along;
 //   C  the wanted rank, now known exactly (n is the count of kept elements), must fall inside the collected keys;
 //      the keys at that position and the next one are found by a 4 x 8-bit radix select over the collected keys of
 //      all quantiles at once (the next position may be the smallest key above the bracket).
 // If a bracket misses (rank outside, more keys than slots, fewer than 64 samples kept) the row is redone by the three-pass
 // select above: same result, three passes.  Exact order statistics by integer counting, as before: bit-equal to
 // torch.nanquantile in the same tests.
-constexpr int QCAND = 24576;
-constexpr int QSAMP = QT3;
+constexpr int QCAND = 30720;           // collected keys of all quantiles of a row (120 KB of LDS)
+constexpr int QSAMP = 4 * QT3;         // samples per row (four per thread)
 
 template <typename F>
 __device__ __forceinline__ void row_visit(const QuantArgs& a, const float* row, const float* lma, const float* lmb, F&& f) {
@@ -934,16 +935,20 @@ __global__ __launch_bounds__(QT3) void quantiles_sample_kernel(QuantJobs jobs) {
     // ------------------------------------------------------------------------------------------------ S: sample and brackets
     {
         const int stride = (N + QSAMP - 1) / QSAMP;
-        const int i = tid * stride + (stride >> 1);
-        unsigned key = QNONE;                              // not a sample: sorts behind every real key
-        if (i < N) {
-            const float v = row[(int64_t)i * a.s_elem];
-            bool keep = v == v;
-            if (keep && masked) keep = ((lma[i / a.P] * lmb[i % a.P]) != 0.f) == (a.want != 0);
-            if (keep) key = f2key(v);
+        int sn = 0;
+#pragma unroll
+        for (int u = 0; u < QSAMP / QT3; ++u) {
+            const int i = (tid + u * QT3) * stride + (stride >> 1);
+            unsigned key = QNONE;                          // not a sample: sorts behind every real key
+            if (i < N) {
+                const float v = row[(int64_t)i * a.s_elem];
+                bool keep = v == v;
+                if (keep && masked) keep = ((lma[i / a.P] * lmb[i % a.P]) != 0.f) == (a.want != 0);
+                if (keep) key = f2key(v);
+            }
+            skey[tid + u * QT3] = key;
+            sn += __syncthreads_count(key != QNONE);       // (the last one is also the barrier after the stores)
         }
-        skey[tid] = key;
-        const int sn = __syncthreads_count(key != QNONE);  // (also the barrier after the store)
         if (sn < 64) {
             if (tid == 0) s_fail = 1;
         } else if (tid < 2 * NQ) {
@@ -961,7 +966,7 @@ __global__ __launch_bounds__(QT3) void quantiles_sample_kernel(QuantJobs jobs) {
         if (tid == 0) s_cntS = QSAMP;
     }
     __syncthreads();
-    if (s_fail) { row_three_pass(a, r, lma, lmb); return; }
+    if (s_fail) { row_three_pass(a, r, lma, lmb, cand, reinterpret_cast<unsigned (*)[QB1]>(cand + QB0)); return; }
     select_targets(skey, 0, &s_cntS, t_list, 2 * NQ, hsel, t_prefix, t_rank);
     if (tid < 2 * NQ) {
         const int j = tid >> 1;
@@ -969,7 +974,7 @@ __global__ __launch_bounds__(QT3) void quantiles_sample_kernel(QuantJobs jobs) {
         else s_lo[j] = t_kind[tid] ? 0u : t_prefix[tid];
     }
     __syncthreads();
-    if (s_fail) { row_three_pass(a, r, lma, lmb); return; }
+    if (s_fail) { row_three_pass(a, r, lma, lmb, cand, reinterpret_cast<unsigned (*)[QB1]>(cand + QB0)); return; }
     // ------------------------------------------------------------------------------------------------ B: the one pass
     // keys EQUAL to a bracket end are counted, not stored: a row of a few distinct values (the dense logits of a freshly
     // initialised encoder) has brackets whose ends are those values, and nothing strictly inside
@@ -1066,7 +1071,7 @@ __global__ __launch_bounds__(QT3) void quantiles_sample_kernel(QuantJobs jobs) {
         }
     }
     __syncthreads();
-    if (s_fail) { row_three_pass(a, r, lma, lmb); return; }
+    if (s_fail) { row_three_pass(a, r, lma, lmb, cand, reinterpret_cast<unsigned (*)[QB1]>(cand + QB0)); return; }
     select_targets(cand, CAP, s_cnt, t_list, 2 * NQ, hsel, t_prefix, t_rank);
     if (tid < NQ) {
         const int j = tid;
@@ -1163,7 +1168,8 @@ static int quant_launch(QuantJobs& jobs, int njobs, int form, void* workspace, i
         for (int j = njobs; j <= QJOBS; ++j) jobs.first_row[j] = rows;
         if (form == 0) {                                   // default: one classifying pass per row (three-pass select as fall-back)
             const size_t lds2 = ((lds + 15) & ~(size_t)15) + (size_t)(QCAND + QSAMP) * sizeof(unsigned);
-            constexpr int kMaxDyn = 110 * 1024;              // + ~41 KB of static LDS (the fall-back's histograms): under the 160 KB of a CU
+            constexpr int kMaxDyn = 148 * 1024;              // + ~9 KB of static LDS: under the 160 KB of a CU (the fall-back's
+                                                             // histograms alias the candidate slots)
             if (lds2 <= (size_t)kMaxDyn) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(quantiles_sample_kernel),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDyn);
