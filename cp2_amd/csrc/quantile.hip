@@ -865,6 +865,24 @@ __device__ __forceinline__ void row_visit(const QuantArgs& a, const float* row, 
     }
 }
 
+// h[bin] += 1 for the lanes with pred, called by all lanes of a wave together.  The keys of a row share their leading
+// digits (every key of a narrow band, most keys of any row at the first levels), and 64 lanes adding to ONE LDS address are
+// served one after the other: the two most common bins of the wave are therefore added once each, with the lane count.
+__device__ __forceinline__ void hist_add_wave(unsigned* h, unsigned bin, bool pred) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const unsigned long long act = __ballot(pred);
+        if (!act) return;
+        const int leader = __ffsll((long long)act) - 1;
+        const unsigned b0 = (unsigned)__shfl((int)bin, leader, 64);
+        const unsigned long long same = __ballot(pred && bin == b0);
+        if (lane == leader) atomicAdd(&h[b0], (unsigned)__popcll(same));
+        pred = pred && bin != b0;
+    }
+    if (pred) atomicAdd(&h[bin], 1u);
+}
+
 // Keys at given ranks of key lists held in LDS, for up to 2 * QMAX targets at once: four levels of eight bits; target t
 // looks at list t_list[t] (keys at lists + t_list[t] * stride, counts[t_list[t]] of them) and wants the key of rank
 // t_rank[t] (0-based).  On return t_prefix[t] is that key.  One wave per target does the scan of a level.
@@ -879,9 +897,11 @@ __device__ __forceinline__ void select_targets(const unsigned* lists, int stride
             const int l = t_list[t];
             const unsigned cnt = counts[l], pre = t_prefix[t];
             const unsigned* keys = lists + l * stride;
-            for (unsigned i = tid; i < cnt; i += QT3) {
-                const unsigned k = keys[i];
-                if (level == 0 || (k >> (shift + 8)) == pre) atomicAdd(&hsel[t][(k >> shift) & 255u], 1u);
+            for (unsigned base = 0; base < cnt; base += QT3) {   // wave-uniform trip count: hist_add_wave votes
+                const unsigned i = base + tid;
+                const unsigned k = i < cnt ? keys[i] : 0u;
+                const bool hit = i < cnt && (level == 0 || (k >> (shift + 8)) == pre);
+                hist_add_wave(hsel[t], (k >> shift) & 255u, hit);
             }
         }
         __syncthreads();
