@@ -402,15 +402,24 @@ __global__ __launch_bounds__(QT3) void quantile_select_kernel(QuantJobs jobs) {
 // on narrow-band rows -- 70 us instead of 63-66: the passes are bound by their ~30 VALU instructions per element on the
 // one CU a row has, not by atomic conflicts.)
 constexpr int QROW_MAX = CP2_QUANTILES_ROW_MAX;
-// The three-level select of one row by one 1024-thread workgroup (the body of quantiles_row_kernel; also the fall-back of
-// quantiles_sample_kernel).  lma / lmb: the row's masks in LDS (loaded by the caller when the job is masked).
-__device__ __forceinline__ void row_three_pass(const QuantArgs& a, const int r, float* lma, float* lmb, unsigned* hist0,
-                                               unsigned (*hist)[QB1]) {
+__global__ __launch_bounds__(QT3) void quantiles_row_kernel(QuantJobs jobs) {
+    int jsel = 0;
+#pragma unroll
+    for (int j = 1; j < QJOBS; ++j) jsel += ((int)blockIdx.x >= jobs.first_row[j]) ? 1 : 0;
+    const QuantArgs& a = jobs.job[jsel];
+    extern __shared__ __attribute__((aligned(16))) unsigned char q_smem[];
+    __shared__ unsigned hist0[QB0];
+    __shared__ unsigned hist[QMAX][QB1];
     __shared__ unsigned wtot[16];
     __shared__ unsigned sh_prefix[QMAX], sh_k[QMAX], sh_min[QMAX], sh_next[QMAX], sh_n;
-    const int tid = threadIdx.x, NQ = a.NQ;
+    float* lma = reinterpret_cast<float*>(q_smem);
+    float* lmb = lma + (a.want >= 0 ? a.P : 0);
+    const int r = (int)blockIdx.x - jobs.first_row[jsel], tid = threadIdx.x, NQ = a.NQ;
     const float* row = a.x + (int64_t)r * a.s_row;
     const bool masked = a.want >= 0;
+    if (masked) {
+        for (int i = tid; i < a.P; i += QT3) { lma[i] = a.mask_a[(int64_t)r * a.P + i]; lmb[i] = a.mask_b[(int64_t)r * a.P + i]; }
+    }
     for (int i = tid; i < QB0; i += QT3) hist0[i] = 0;
     __syncthreads();
     const bool vec = a.s_elem == 1 && ((reinterpret_cast<uintptr_t>(row) & 15u) == 0);
@@ -563,23 +572,6 @@ __device__ __forceinline__ void row_three_pass(const QuantArgs& a, const int r, 
         a.out[(int64_t)j * a.R + r] = (w < 0.5f) ? v_lo + w * d : v_hi - d * (1.f - w);
     }
 #undef CP2_Q_FOREACH
-}
-
-__global__ __launch_bounds__(QT3) void quantiles_row_kernel(QuantJobs jobs) {
-    int jsel = 0;
-#pragma unroll
-    for (int j = 1; j < QJOBS; ++j) jsel += ((int)blockIdx.x >= jobs.first_row[j]) ? 1 : 0;
-    const QuantArgs& a = jobs.job[jsel];
-    extern __shared__ __attribute__((aligned(16))) unsigned char q_smem[];
-    float* lma = reinterpret_cast<float*>(q_smem);
-    float* lmb = lma + (a.want >= 0 ? a.P : 0);
-    const int r = (int)blockIdx.x - jobs.first_row[jsel];
-    if (a.want >= 0) {
-        for (int i = threadIdx.x; i < a.P; i += QT3) { lma[i] = a.mask_a[(int64_t)r * a.P + i]; lmb[i] = a.mask_b[(int64_t)r * a.P + i]; }
-    }
-    __shared__ unsigned hist0[QB0];
-    __shared__ unsigned hist[QMAX][QB1];
-    row_three_pass(a, r, lma, lmb, hist0, hist);
 }
 
 // ---- rows of at most QROW_MAX elements, a few hundred chunks in total (the training step: 576): ONE launch, one
@@ -792,330 +784,6 @@ __global__ __launch_bounds__(QT1, 3) void quantiles_coop_kernel(QuantJobs jobs) 
     if (tid == 0 && atomicAdd(&sel[1], 1u) == (unsigned)G - 1u) { atomicExch(&sel[0], 0u); atomicExch(&sel[1], 0u); }
 }
 
-// ---- rows of at most QROW_MAX elements, round 3: ONE pass over the row instead of three.
-// A workgroup per row, as quantiles_row_kernel, but the bulk of the row is only CLASSIFIED:
-//   S  4096 samples of the row (stride N / 4096); for each quantile q the samples of rank q (s-1) -+ 4 sqrt(q (1-q) s), found
-//      by a radix select over the samples, become a bracket [lo, hi] in key space (about 8 n / sqrt(s) = n / 8 ... n / 16 keys): it holds the wanted order statistic with probability 1 - 6e-5, whatever the distribution (narrow bands and
-//      rows of a few distinct values included: the bracket is made of values of the row itself);
-//   B  the one pass: per quantile count the keys below the bracket, keep the smallest key above it, and collect the keys
-//      strictly inside it in LDS (30720 slots for all quantiles of the row; keys equal to a bracket end are counted, so a
-//      row of a few distinct values stores nothing); the row sum rides along;
-//   C  the wanted rank, now known exactly (n is the count of kept elements), must fall inside the collected keys;
-//      the keys at that position and the next one are found by a 4 x 8-bit radix select over the collected keys of
-//      all quantiles at once (the next position may be the smallest key above the bracket).
-// If a bracket misses (rank outside, more keys than slots, fewer than 64 samples kept) the row is redone by the three-pass
-// select above: same result, three passes.  Exact order statistics by integer counting, as before: bit-equal to
-// torch.nanquantile in the same tests.
-constexpr int QCAND = 30720;           // collected keys of all quantiles of a row (120 KB of LDS)
-constexpr int QSAMP = 4 * QT3;         // samples per row (four per thread)
-
-template <typename F>
-__device__ __forceinline__ void row_visit(const QuantArgs& a, const float* row, const float* lma, const float* lmb, F&& f) {
-    const int tid = threadIdx.x;
-    const bool masked = a.want >= 0, wantpos = a.want != 0;
-    const bool vec = a.s_elem == 1 && ((reinterpret_cast<uintptr_t>(row) & 15u) == 0);
-    if (vec) {
-        const int n4 = (a.N + 3) >> 2;
-        for (int j4 = tid; j4 < n4; j4 += 4 * QT3) {
-            float4 t4[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {                  // four 16-byte loads in flight
-                const int i0 = (j4 + g * QT3) * 4;
-                if (i0 + 3 < a.N) {
-                    t4[g] = *reinterpret_cast<const float4*>(row + i0);
-                } else {
-                    t4[g].x = (i0 + 0 < a.N) ? row[i0 + 0] : NAN;
-                    t4[g].y = (i0 + 1 < a.N) ? row[i0 + 1] : NAN;
-                    t4[g].z = (i0 + 2 < a.N) ? row[i0 + 2] : NAN;
-                    t4[g].w = NAN;
-                }
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int i0 = (j4 + g * QT3) * 4;
-                const float vv[4] = {t4[g].x, t4[g].y, t4[g].z, t4[g].w};
-                int x_ = masked ? i0 / a.P : 0, y_ = masked ? i0 % a.P : 0;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float v = vv[u];
-                    bool keep = v == v;                    // nanquantile ignores NaN (also the padding above)
-                    if (keep && masked) keep = ((lma[x_] * lmb[y_]) != 0.f) == wantpos;
-                    if (keep) f(v);
-                    if (masked && ++y_ >= a.P) { y_ = 0; ++x_; }
-                }
-            }
-        }
-    } else {
-        for (int i0 = tid; i0 < a.N; i0 += 4 * QT3) {
-            float vv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * QT3;
-                vv[u] = i < a.N ? row[(int64_t)i * a.s_elem] : NAN;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * QT3;
-                const float v = vv[u];
-                bool keep = v == v;
-                if (keep && masked) keep = ((lma[i / a.P] * lmb[i % a.P]) != 0.f) == wantpos;
-                if (keep) f(v);
-            }
-        }
-    }
-}
-
-// h[bin] += 1 for the lanes with pred, called by all lanes of a wave together.  The keys of a row share their leading
-// digits (every key of a narrow band, most keys of any row at the first levels), and 64 lanes adding to ONE LDS address are
-// served one after the other: the two most common bins of the wave are therefore added once each, with the lane count.
-__device__ __forceinline__ void hist_add_wave(unsigned* h, unsigned bin, bool pred) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const unsigned long long act = __ballot(pred);
-        if (!act) return;
-        const int leader = __ffsll((long long)act) - 1;
-        const unsigned b0 = (unsigned)__shfl((int)bin, leader, 64);
-        const unsigned long long same = __ballot(pred && bin == b0);
-        if (lane == leader) atomicAdd(&h[b0], (unsigned)__popcll(same));
-        pred = pred && bin != b0;
-    }
-    if (pred) atomicAdd(&h[bin], 1u);
-}
-
-// Keys at given ranks of key lists held in LDS, for up to 2 * QMAX targets at once: four levels of eight bits; target t
-// looks at list t_list[t] (keys at lists + t_list[t] * stride, counts[t_list[t]] of them) and wants the key of rank
-// t_rank[t] (0-based).  On return t_prefix[t] is that key.  One wave per target does the scan of a level.
-__device__ __forceinline__ void select_targets(const unsigned* lists, int stride, const unsigned* counts, const int* t_list, int nt,
-                                               unsigned (*hsel)[256], unsigned* t_prefix, unsigned* t_rank) {
-    const int tid = threadIdx.x;
-    for (int level = 0; level < 4; ++level) {
-        const int shift = 24 - 8 * level;
-        for (int i = tid; i < 2 * QMAX * 256; i += QT3) (&hsel[0][0])[i] = 0;
-        __syncthreads();
-        for (int t = 0; t < nt; ++t) {
-            const int l = t_list[t];
-            const unsigned cnt = counts[l], pre = t_prefix[t];
-            const unsigned* keys = lists + l * stride;
-            for (unsigned base = 0; base < cnt; base += QT3) {   // wave-uniform trip count: hist_add_wave votes
-                const unsigned i = base + tid;
-                const unsigned k = i < cnt ? keys[i] : 0u;
-                const bool hit = i < cnt && (level == 0 || (k >> (shift + 8)) == pre);
-                hist_add_wave(hsel[t], (k >> shift) & 255u, hit);
-            }
-        }
-        __syncthreads();
-        const int t = tid >> 6, lane = tid & 63;
-        if (t < nt) {
-            const unsigned h0 = hsel[t][4 * lane], h1 = hsel[t][4 * lane + 1], h2 = hsel[t][4 * lane + 2], h3 = hsel[t][4 * lane + 3];
-            const unsigned tot = h0 + h1 + h2 + h3;
-            unsigned incl = tot;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const unsigned up = (unsigned)__shfl_up((int)incl, off, 64);
-                if (lane >= off) incl += up;
-            }
-            const unsigned excl = incl - tot, want = t_rank[t];
-            if (want >= excl && want < incl) {
-                unsigned kk = want - excl, b = 4 * lane;
-                if (kk >= h0) { kk -= h0; ++b; if (kk >= h1) { kk -= h1; ++b; if (kk >= h2) { kk -= h2; ++b; } } }
-                t_prefix[t] = (t_prefix[t] << 8) | b;
-                t_rank[t] = kk;
-            }
-        }
-        __syncthreads();
-    }
-}
-
-__global__ __launch_bounds__(QT3) void quantiles_sample_kernel(QuantJobs jobs) {
-    int jsel = 0;
-#pragma unroll
-    for (int j = 1; j < QJOBS; ++j) jsel += ((int)blockIdx.x >= jobs.first_row[j]) ? 1 : 0;
-    const QuantArgs& a = jobs.job[jsel];
-    extern __shared__ __attribute__((aligned(16))) unsigned char q_smem[];
-    const int r = (int)blockIdx.x - jobs.first_row[jsel], tid = threadIdx.x, NQ = a.NQ, N = a.N;
-    const bool masked = a.want >= 0;
-    float* lma = reinterpret_cast<float*>(q_smem);
-    float* lmb = lma + (masked ? a.P : 0);
-    unsigned* cand = reinterpret_cast<unsigned*>(lma + (masked ? ((2 * a.P + 3) & ~3) : 0));      // [NQ][CAP]
-    unsigned* skey = cand + QCAND;                                                                // [QSAMP]
-    __shared__ unsigned s_cnt[QMAX], s_below[QMAX], s_above[QMAX], s_lo[QMAX], s_hi[QMAX], s_eqlo[QMAX], s_eqhi[QMAX], s_n, s_fail;
-    __shared__ unsigned hsel[2 * QMAX][256];
-    __shared__ unsigned t_prefix[2 * QMAX], t_rank[2 * QMAX], t_kind[2 * QMAX], s_cntS;
-    __shared__ int t_list[2 * QMAX];
-    __shared__ double sum_w[QT3 / 64];
-    const float* row = a.x + (int64_t)r * a.s_row;
-    if (masked) {
-        for (int i = tid; i < a.P; i += QT3) { lma[i] = a.mask_a[(int64_t)r * a.P + i]; lmb[i] = a.mask_b[(int64_t)r * a.P + i]; }
-    }
-    if (tid < QMAX) { s_cnt[tid] = 0; s_below[tid] = 0; s_above[tid] = QNONE; s_lo[tid] = 0; s_hi[tid] = QNONE; s_eqlo[tid] = 0; s_eqhi[tid] = 0; }
-    if (tid == 0) { s_n = 0; s_fail = 0; }
-    __syncthreads();
-    const int CAP = QCAND / NQ;
-    // ------------------------------------------------------------------------------------------------ S: sample and brackets
-    {
-        const int stride = (N + QSAMP - 1) / QSAMP;
-        int sn = 0;
-#pragma unroll
-        for (int u = 0; u < QSAMP / QT3; ++u) {
-            const int i = (tid + u * QT3) * stride + (stride >> 1);
-            unsigned key = QNONE;                          // not a sample: sorts behind every real key
-            if (i < N) {
-                const float v = row[(int64_t)i * a.s_elem];
-                bool keep = v == v;
-                if (keep && masked) keep = ((lma[i / a.P] * lmb[i % a.P]) != 0.f) == (a.want != 0);
-                if (keep) key = f2key(v);
-            }
-            skey[tid + u * QT3] = key;
-            sn += __syncthreads_count(key != QNONE);       // (the last one is also the barrier after the stores)
-        }
-        if (sn < 64) {
-            if (tid == 0) s_fail = 1;
-        } else if (tid < 2 * NQ) {
-            // targets 2j / 2j+1: the samples of rank q (sn-1) -+ 4 sqrt(q (1-q) sn) (- 2 / + 2); a rank outside the sample
-            // leaves that end open.  The invalid slots of the sample hold QNONE and sort behind every real key.
-            const int j = tid >> 1, up = tid & 1;
-            const float qj = a.q[j];
-            const float rho = qj * (float)(sn - 1), m = 4.f * sqrtf(fmaxf(qj * (1.f - qj), 0.f) * (float)sn) + 2.f;
-            const int rk = up ? (int)ceilf(rho + m) : (int)floorf(rho - m);
-            t_list[tid] = 0;
-            t_prefix[tid] = 0;
-            t_kind[tid] = (rk < 0 || rk >= sn) ? 1u : 0u;   // 1: open end
-            t_rank[tid] = (unsigned)min(max(rk, 0), sn - 1);
-        }
-        if (tid == 0) s_cntS = QSAMP;
-    }
-    __syncthreads();
-    if (s_fail) { row_three_pass(a, r, lma, lmb, cand, reinterpret_cast<unsigned (*)[QB1]>(cand + QB0)); return; }
-    select_targets(skey, 0, &s_cntS, t_list, 2 * NQ, hsel, t_prefix, t_rank);
-    if (tid < 2 * NQ) {
-        const int j = tid >> 1;
-        if (tid & 1) s_hi[j] = t_kind[tid] ? QNONE : t_prefix[tid];
-        else s_lo[j] = t_kind[tid] ? 0u : t_prefix[tid];
-    }
-    __syncthreads();
-    if (s_fail) { row_three_pass(a, r, lma, lmb, cand, reinterpret_cast<unsigned (*)[QB1]>(cand + QB0)); return; }
-    // ------------------------------------------------------------------------------------------------ B: the one pass
-    // keys EQUAL to a bracket end are counted, not stored: a row of a few distinct values (the dense logits of a freshly
-    // initialised encoder) has brackets whose ends are those values, and nothing strictly inside
-    unsigned lo[QMAX], hi[QMAX], below[QMAX], amin[QMAX], eqlo[QMAX], eqhi[QMAX];
-#pragma unroll
-    for (int j = 0; j < QMAX; ++j) {
-        lo[j] = j < NQ ? s_lo[j] : 0u; hi[j] = j < NQ ? s_hi[j] : QNONE;
-        below[j] = 0; amin[j] = QNONE; eqlo[j] = 0; eqhi[j] = 0;
-    }
-    unsigned nkept = 0;
-    float lsum = 0.f;
-    row_visit(a, row, lma, lmb, [&](float v) {
-        const unsigned k = f2key(v);
-        ++nkept;
-        lsum += v;
-#pragma unroll
-        for (int j = 0; j < QMAX; ++j) {
-            if (j < NQ) {
-                if (k < lo[j]) ++below[j];
-                else if (k == lo[j]) ++eqlo[j];
-                else if (k == hi[j]) ++eqhi[j];
-                else if (k > hi[j]) amin[j] = min(amin[j], k);
-                // strictly inside: one LDS atomic per wave and quantile reserves the slots of all its lanes
-                const bool in = k > lo[j] && k < hi[j];
-                const unsigned long long mk = __ballot(in);
-                if (mk) {
-                    const int lane = tid & 63, leader = __ffsll((long long)mk) - 1;
-                    unsigned base = 0;
-                    if (lane == leader) base = atomicAdd(&s_cnt[j], (unsigned)__popcll(mk));
-                    base = (unsigned)__shfl((int)base, leader, 64);
-                    const unsigned idx = base + (unsigned)__popcll(mk & ((1ull << lane) - 1ull));
-                    if (in && idx < (unsigned)CAP) cand[j * CAP + idx] = k;
-                }
-            }
-        }
-    });
-    {
-        unsigned nk = nkept;
-        double ds = (double)lsum;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            nk += (unsigned)__shfl_xor((int)nk, off, 64);
-            ds += __shfl_xor(ds, off, 64);
-        }
-        if ((tid & 63) == 0) { atomicAdd(&s_n, nk); sum_w[tid >> 6] = ds; }
-#pragma unroll
-        for (int j = 0; j < QMAX; ++j) {
-            if (j < NQ) {
-                unsigned b = below[j], m = amin[j], el = eqlo[j], eh = eqhi[j];
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    b += (unsigned)__shfl_xor((int)b, off, 64);
-                    el += (unsigned)__shfl_xor((int)el, off, 64);
-                    eh += (unsigned)__shfl_xor((int)eh, off, 64);
-                    m = min(m, (unsigned)__shfl_xor((int)m, off, 64));
-                }
-                if ((tid & 63) == 0) {
-                    atomicAdd(&s_below[j], b); atomicAdd(&s_eqlo[j], el); atomicAdd(&s_eqhi[j], eh);
-                    if (m != QNONE) atomicMin(&s_above[j], m);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    const unsigned n = s_n;
-    if (n == 0) {
-        if (tid < NQ) a.out[(int64_t)tid * a.R + r] = NAN;
-        if (a.mean_out && tid == 0) a.mean_out[r] = NAN;
-        return;
-    }
-    // ------------------------------------------------------------------------------------------------ C: ranks inside the brackets
-    // sorted content of bracket j: [eqlo copies of lo][the cnt stored keys, strictly inside][eqhi copies of hi], then the keys
-    // above it.  Positions L - below and L - below + 1 are each: 0 = lo, 1 = a stored key (radix select), 2 = hi, 3 = above.
-    if (tid < NQ) {
-        const int j = tid;
-        const float rank = a.q[j] * (float)(n - 1);
-        const unsigned L = (unsigned)floorf(rank), cnt = s_cnt[j], bl = s_below[j], el = s_eqlo[j], eh = s_eqhi[j];
-        if (cnt > (unsigned)CAP || L < bl || L - bl >= el + cnt + eh) {
-            atomicExch(&s_fail, 1u);
-        } else {
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const unsigned pos = L - bl + u;
-                unsigned kind, rk = 0;
-                if (pos < el) kind = 0;
-                else if (pos < el + cnt) { kind = 1; rk = pos - el; }
-                else if (pos < el + cnt + eh) kind = 2;
-                else kind = 3;
-                t_kind[2 * j + u] = kind;
-                t_rank[2 * j + u] = rk;
-                t_prefix[2 * j + u] = 0;
-                t_list[2 * j + u] = j;
-            }
-        }
-    }
-    __syncthreads();
-    if (s_fail) { row_three_pass(a, r, lma, lmb, cand, reinterpret_cast<unsigned (*)[QB1]>(cand + QB0)); return; }
-    select_targets(cand, CAP, s_cnt, t_list, 2 * NQ, hsel, t_prefix, t_rank);
-    if (tid < NQ) {
-        const int j = tid;
-        const float rank = a.q[j] * (float)(n - 1);
-        const float lo_f = floorf(rank), w = rank - lo_f;
-        auto value = [&](int t, float dflt) -> float {
-            const unsigned kind = t_kind[t];
-            if (kind == 0) return key2f(s_lo[j]);
-            if (kind == 1) return key2f(t_prefix[t]);
-            if (kind == 2) return key2f(s_hi[j]);
-            return s_above[j] != QNONE ? key2f(s_above[j]) : dflt;
-        };
-        const float v_lo = value(2 * j, 0.f);
-        const float v_hi = w != 0.f ? value(2 * j + 1, v_lo) : v_lo;
-        const float d = v_hi - v_lo;                         // at::lerp: w < 0.5 ? a + w*(b-a) : b - (b-a)*(1-w)
-        a.out[(int64_t)j * a.R + r] = (w < 0.5f) ? v_lo + w * d : v_hi - d * (1.f - w);
-    }
-    if (a.mean_out && tid == 0) {
-        double t = 0;
-        for (int i = 0; i < QT3 / 64; ++i) t += sum_w[i];
-        a.mean_out[r] = (n == (unsigned)N) ? (float)(t / (double)N) : NAN;   // a NaN element makes torch's mean NaN
-    }
-}
-
 static int quant_check(const QuantArgs& a) {
     if (!a.x || !a.q || !a.out) return CP2_ERR_NULL;
     if (a.R <= 0 || a.N <= 0 || a.NQ <= 0) return CP2_ERR_SHAPE;
@@ -1138,7 +806,7 @@ CP2_API int64_t cp2_quantiles_workspace_bytes(int njobs, const int* R, const int
     return 4 * quant_ws_words(njobs, R, N, NQ);
 }
 
-// form: 0 = automatic, 1 = three-pass row kernel, 2 = cooperative chunks (needs the workspace), see cp2hip.h
+// form: 0 = automatic (a workgroup per row for rows up to QROW_MAX), 1 = the same, explicitly, 2 = cooperative chunks
 static int quant_launch(QuantJobs& jobs, int njobs, int form, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
     bool small = true;
     for (int j = 0; j < njobs; ++j) small = small && jobs.job[j].N <= QROW_MAX;
@@ -1186,18 +854,6 @@ static int quant_launch(QuantJobs& jobs, int njobs, int form, void* workspace, i
             rows += jobs.job[j].R;
         }
         for (int j = njobs; j <= QJOBS; ++j) jobs.first_row[j] = rows;
-        if (form == 0) {                                   // default: one classifying pass per row (three-pass select as fall-back)
-            const size_t lds2 = ((lds + 15) & ~(size_t)15) + (size_t)(QCAND + QSAMP) * sizeof(unsigned);
-            constexpr int kMaxDyn = 148 * 1024;              // + ~9 KB of static LDS: under the 160 KB of a CU (the fall-back's
-                                                             // histograms alias the candidate slots)
-            if (lds2 <= (size_t)kMaxDyn) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(quantiles_sample_kernel),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDyn);
-                if (e != hipSuccess) return (int)e;
-                CP2_LAUNCH_PROFILED(quantiles_sample_kernel, dim3(rows), dim3(QT3), lds2, stream, jobs);
-                return cp2_launch_status();
-            }
-        }
         CP2_LAUNCH_PROFILED(quantiles_row_kernel, dim3(rows), dim3(QT3), lds, stream, jobs);
         return cp2_launch_status();
     }
@@ -1259,4 +915,3 @@ CP2_API int cp2_masked_quantiles_multi(int njobs, const float* const* x, const i
                                 mean_out ? mean_out[j] : nullptr};
     return quant_launch(jobs, njobs, form, workspace, workspace_bytes, cp2_stream(stream));
 }
-

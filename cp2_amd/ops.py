@@ -715,9 +715,9 @@ def _quartile_tensor(device) -> torch.Tensor:
 _QUANT_WS = {}
 QUANTILES_ROW_MAX = 131072     # CP2_QUANTILES_ROW_MAX
 QUANTILES_CHUNK = 8192         # QCHUNK in csrc/quantile.hip
-QUANTILES_FORM = 0             # one-launch form for rows up to QUANTILES_ROW_MAX: 0 = one classifying pass per row (sample
-                               # brackets; the product path), 1 = three-pass row kernel (round 2), 2 = cooperative chunks with
-                               # row-local barriers (58.9 us against 63.2 us for form 1; needs a workspace).  Identical results.
+QUANTILES_FORM = 0             # one-launch form for rows up to QUANTILES_ROW_MAX: 0 / 1 = one workgroup per row through the three
+                               # levels (the product path), 2 = one workgroup per chunk with row-local barriers (58.9 us against
+                               # 63.2 us; needs a workspace; not the default because of its spin-waits).  Identical results.
 QUANTILES_COOP_MAX_WGS = 768   # QCOOP_MAX_WGS: up to this many chunk workgroups the one-launch cooperative form is taken
 
 

