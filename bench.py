@@ -230,8 +230,6 @@ def main():
     runner = TrainStep(wrapped, opt)
     if os.environ.get("CP2_BENCH_QUART", "1") != "1":
         model.log_quartiles = False
-    from cp2_amd import functional as CF
-    CF.OVERLAP_STATS = os.environ.get("CP2_OVERLAP_STATS", "1") == "1"      # A/B: quartile launch on a side stream
 
     # the EMA is hoisted in front of the rest of the step so each of its launches can be bracketed by HIP events on the
     # launch stream; it reads theta_q after the previous optimizer step and runs before the key encoder, exactly where

@@ -47,17 +47,6 @@ S_LOSS, S_LOSS_INS, S_LOSS_DENSE, S_ACC1, S_ACC5, S_ACC_DENSE, S_POS_SCORE, S_NE
 S_VAR_SRC, S_VAR_TGT, S_DPOS_Q, S_DNEG_Q, S_INS_Q, S_INS_NEG_MEAN = 9, 10, 11, 14, 17, 20
 
 
-OVERLAP_STATS = True       # quartile launch on a side stream beside the gradient kernels (A/B: False = in line)
-_STATS_STREAMS = {}
-
-
-def _stats_stream(device) -> torch.cuda.Stream:
-    key = torch.device(device).index
-    if key not in _STATS_STREAMS:
-        _STATS_STREAMS[key] = torch.cuda.Stream(device=device)
-    return _STATS_STREAMS[key]
-
-
 class _CP2LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q_feat, k_feat, mask_a, mask_b, queue, cfg):
@@ -90,32 +79,6 @@ class _CP2LossFn(torch.autograd.Function):
             neg = (nscale, centre)
         den = ops.dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temp_local, ids, weights, want_logits=want_quart,
                                     negative=neg, want_batch=False)
-        # The logging quartiles (reference tools/correlation_mapping.py:16-53, builder.py:1399-1406) depend on the logits
-        # only: their launch -- the longest kernel of the section, 96 workgroups on 256 CUs -- goes to a side HIP stream and
-        # runs beside the gradient kernels below instead of in front of the step's scalars
-        qs = (None, None, None)
-        lneg_mean = joined = None
-        if want_quart:
-            K = queue.shape[1]
-            dense = dict(x=den.logits, stride_row=P * P, stride_elem=1, R=B, N=P * P, mask_a=mask_a, mask_b=mask_b)
-            row_form = K <= ops.QUANTILES_ROW_MAX and P * P <= ops.QUANTILES_ROW_MAX
-            lneg_mean = torch.empty(B, dtype=torch.float32, device=q_feat.device) if row_form else ins.lneg.mean(1)
-            jobs = [dict(dense, want=1), dict(dense, want=0),                                 # one launch for all three
-                    dict(x=ins.lneg, stride_row=K, stride_elem=1, R=B, N=K, mean_out=lneg_mean if row_form else None)]
-            cur = torch.cuda.current_stream()
-            if OVERLAP_STATS and row_form and not torch.cuda.is_current_stream_capturing():
-                side = _stats_stream(q_feat.device)
-                side.wait_stream(cur)
-                with torch.cuda.stream(side):
-                    qs = ops.masked_quantiles_multi(jobs)
-                    joined = torch.cuda.Event()
-                    joined.record(side)
-                for t in (den.logits, ins.lneg, mask_a, mask_b, lneg_mean):
-                    t.record_stream(side)                        # read / written over there: not to be recycled before it is done
-                for t in qs:
-                    t.record_stream(cur)                         # allocated over there, read here
-            else:
-                qs = ops.masked_quantiles_multi(jobs)
         if need_grad:
             # the dense kernel's split gradients stay un-summed: feat_bwd_fused adds them, and computes the pooled-vector
             # backward per workgroup (round 2: dense_grad_sum + pool_bwd + two fill kernels for dE)
@@ -124,8 +87,16 @@ class _CP2LossFn(torch.autograd.Function):
             dq = ops.feat_bwd_fused(q_dense, q_inv, mask_a, g_part, S, ins.drows, ins.dE, q_pos, q_neg, k_pos, k_neg, q_norms,
                                     include_background, q_feat)
             ctx.save_for_backward(dq)
-        if joined is not None:
-            torch.cuda.current_stream().wait_event(joined)       # the quartiles (side stream) before the scalars that average them
+        qs = (None, None, None)
+        lneg_mean = None
+        if want_quart:
+            K = queue.shape[1]
+            dense = dict(x=den.logits, stride_row=P * P, stride_elem=1, R=B, N=P * P, mask_a=mask_a, mask_b=mask_b)
+            row_form = K <= ops.QUANTILES_ROW_MAX and P * P <= ops.QUANTILES_ROW_MAX
+            lneg_mean = torch.empty(B, dtype=torch.float32, device=q_feat.device) if row_form else ins.lneg.mean(1)
+            qs = ops.masked_quantiles_multi([dict(dense, want=1), dict(dense, want=0),       # one launch for all three
+                                             dict(x=ins.lneg, stride_row=K, stride_elem=1, R=B, N=K,
+                                                  mean_out=lneg_mean if row_form else None)])
         # every scalar the step returns or logs: one launch (the loss combination included)
         scal = ops.step_scalars(ins.loss, ins.cnt_gt, ext, den.sample_scal, q_pos, k_pos, lmbd_dense, qs[0], qs[1], qs[2], lneg_mean)
         outs = (scal[S_LOSS], scal, k_pos, q_pos, den.sample_scal, extras[:, 0])
