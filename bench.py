@@ -63,6 +63,10 @@ def parse():
                    help="shuffle-BN rows by all-to-all (only the rows a rank keeps travel) or the reference's all-gather form (A/B)")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     p.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    p.add_argument("--rehearse-collectives", action="store_true",
+                   help="N = 1 only: run every collective of the N > 1 step (shuffle exchange, key gathers, DDP all-reduce) over the "
+                        "chosen backend with ONE rank -- no data moves, but every stream hand-over of the multi-GPU step is paid: "
+                        "the plumbing cost of the collectives on this box")
     p.add_argument("--nosync-steps", type=int, default=10,
                    help="N > 1: extra steps under DDP.no_sync() after the timed region (exposed all-reduce time); 0 = skip")
     p.add_argument("--cpu-batch", type=int, default=32, help="CPU baseline: images per step (BASELINE.md section 3: the same b)")
@@ -186,8 +190,15 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    rehearse = args.rehearse_collectives and world == 1
     if world > 1:
         dist.init_process_group(args.backend, rank=rank, world_size=world)
+    elif rehearse:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        dist.init_process_group(args.backend, rank=0, world_size=1)
+        from cp2_amd import dist as cdist
+        cdist.FORCE_COLLECTIVES = True
 
     from cp2_amd import builder, ops, synthetic
     from cp2_amd.encoder import FusedBatchNorm2d
@@ -216,7 +227,7 @@ def main():
     model.train()
     model.shuffle_exchange = args.shuffle_exchange
     wrapped = model
-    if world > 1:
+    if world > 1 or rehearse:
         wrapped = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], output_device=local,
                                                             broadcast_buffers=False, gradient_as_bucket_view=True)
 
@@ -276,7 +287,7 @@ def main():
         one_step(i, False)
     torch.cuda.synchronize()
     ops.PROFILE = {}               # every profiled launch of the timed steps carries its own start/stop hipEvents
-    model.comm_events = {} if world > 1 else None
+    model.comm_events = {} if (world > 1 or rehearse) else None
     dt, loss = timed_region(args.steps, True)
     loss_val = float(loss)
     assert loss_val == loss_val, "loss is NaN"
@@ -284,7 +295,7 @@ def main():
     comm_events, model.comm_events = model.comm_events, None
 
     comm = None
-    if world > 1:
+    if world > 1 or rehearse:
         def ev_ms(name):
             evs = comm_events.get(name) or []
             return round(sum(a.elapsed_time(z) for a, z in evs) / args.steps, 4) if evs else None
@@ -300,6 +311,7 @@ def main():
         frac = (world - 1) / world
         comm = {
             "backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(), "one_device_rehearsal": bool(args.one_device),
+            "single_rank_rehearsal": bool(rehearse),
             "launcher": os.environ.get("CP2_BENCH_LAUNCHER", "external"), "shuffle_exchange": args.shuffle_exchange,
             "overlap_key_branch": args.overlap,
             "ms_per_step": {   # stream time between the events around each exchange step (it includes waiting for peers)
@@ -404,7 +416,7 @@ def main():
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if world > 1:
+    if world > 1 or rehearse:
         dist.destroy_process_group()
 
 
