@@ -67,6 +67,7 @@ def parse():
                    help="N = 1 only: run every collective of the N > 1 step (shuffle exchange, key gathers, DDP all-reduce) over the "
                         "chosen backend with ONE rank -- no data moves, but every stream hand-over of the multi-GPU step is paid: "
                         "the plumbing cost of the collectives on this box")
+    p.add_argument("--bucket-mb", type=int, default=0, help="DDP bucket_cap_mb (0 = the model's default, builder.DDP_BUCKET_MB)")
     p.add_argument("--nosync-steps", type=int, default=10,
                    help="N > 1: extra steps under DDP.no_sync() after the timed region (exposed all-reduce time); 0 = skip")
     p.add_argument("--cpu-batch", type=int, default=32, help="CPU baseline: images per step (BASELINE.md section 3: the same b)")
@@ -229,7 +230,8 @@ def main():
     wrapped = model
     if world > 1 or rehearse:
         wrapped = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], output_device=local,
-                                                            broadcast_buffers=False, gradient_as_bucket_view=True)
+                                                            broadcast_buffers=False, gradient_as_bucket_view=True,
+                                                            bucket_cap_mb=args.bucket_mb or builder.DDP_BUCKET_MB)
 
     class A:  # optimizer settings of reference main.py defaults
         lr, momentum, weight_decay, optim = 0.03, 0.9, 1e-4, "sgd"
@@ -313,7 +315,7 @@ def main():
             "backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(), "one_device_rehearsal": bool(args.one_device),
             "single_rank_rehearsal": bool(rehearse),
             "launcher": os.environ.get("CP2_BENCH_LAUNCHER", "external"), "shuffle_exchange": args.shuffle_exchange,
-            "overlap_key_branch": args.overlap,
+            "overlap_key_branch": args.overlap, "ddp_bucket_mb": args.bucket_mb or builder.DDP_BUCKET_MB,
             "ms_per_step": {   # stream time between the events around each exchange step (it includes waiting for peers)
                 "c1_image_exchange": ev_ms("c1_image_exchange"), "c3_key_unshuffle": ev_ms("c3_key_unshuffle"),
                 "c4_key_gather_enqueue": ev_ms("c4_key_gather_enqueue"),

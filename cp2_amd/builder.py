@@ -33,6 +33,9 @@ from .encoder import build_segmentor
 from .pretrain_types import PretrainType
 
 
+DDP_BUCKET_MB = 25        # bucket_cap_mb main.py / bench.py hand DistributedDataParallel (torch's default)
+
+
 class BackboneType(Enum):
     DEEPLABV3 = 0
     UNET_ENCODER_ONLY = 1
