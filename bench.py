@@ -57,8 +57,9 @@ def parse():
                    help="optimizer step as one HIP launch on the flat parameter buffer (off: torch.optim.SGD) (A/B)")
     p.add_argument("--fused-bn", default="on", choices=["on", "off"], help="encoder fast path: fused BN(+add)(+ReLU) kernels (A/B)")
     p.add_argument("--overlap", default="auto", choices=["auto", "gather", "on", "off"],
-                   help="side HIP stream for the key branch: gather = EMA + shuffle exchange only (auto when N > 1), "
-                        "on = the key encoder too, off = serial (auto at N = 1)")
+                   help="side HIP stream for the key branch: off = everything in order on one stream (auto: measured fastest, also "
+                        "with the collectives of N > 1), gather = EMA + shuffle exchange + key gather on a side stream, on = the key "
+                        "encoder too")
     p.add_argument("--shuffle-exchange", default="all_to_all", choices=["all_to_all", "all_gather"],
                    help="shuffle-BN rows by all-to-all (only the rows a rank keeps travel) or the reference's all-gather form (A/B)")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
@@ -67,7 +68,10 @@ def parse():
                    help="N = 1 only: run every collective of the N > 1 step (shuffle exchange, key gathers, DDP all-reduce) over the "
                         "chosen backend with ONE rank -- no data moves, but every stream hand-over of the multi-GPU step is paid: "
                         "the plumbing cost of the collectives on this box")
-    p.add_argument("--bucket-mb", type=int, default=0, help="DDP bucket_cap_mb (0 = the model's default, builder.DDP_BUCKET_MB)")
+    p.add_argument("--bucket-mb", type=int, default=0, help="gradient bucket size in MB (0 = the model's default, builder.DDP_BUCKET_MB)")
+    p.add_argument("--grad-sync", default="flat", choices=["flat", "ddp"],
+                   help="N > 1: gradient averaging by cp2_amd.ddp.FlatDDP (one pack launch + one all-reduce per bucket of the flat "
+                        "gradient buffer; what cp2_amd.main uses) or by torch's DistributedDataParallel (one copy launch per parameter)")
     p.add_argument("--nosync-steps", type=int, default=10,
                    help="N > 1: extra steps under DDP.no_sync() after the timed region (exposed all-reduce time); 0 = skip")
     p.add_argument("--cpu-batch", type=int, default=32, help="CPU baseline: images per step (BASELINE.md section 3: the same b)")
@@ -228,7 +232,10 @@ def main():
     model.train()
     model.shuffle_exchange = args.shuffle_exchange
     wrapped = model
-    if world > 1 or rehearse:
+    if (world > 1 or rehearse) and args.grad_sync == "flat":
+        from cp2_amd.ddp import FlatDDP
+        wrapped = FlatDDP(model, bucket_mb=args.bucket_mb or builder.DDP_BUCKET_MB)
+    elif world > 1 or rehearse:
         wrapped = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], output_device=local,
                                                             broadcast_buffers=False, gradient_as_bucket_view=True,
                                                             bucket_cap_mb=args.bucket_mb or builder.DDP_BUCKET_MB)
@@ -266,6 +273,8 @@ def main():
             model._momentum_update_key_encoder()
         return runner(batches[i % len(batches)])
 
+    host_issue = [None]
+
     def timed_region(n_steps, timed_kernels):
         if world > 1:
             dist.barrier()
@@ -274,6 +283,7 @@ def main():
         last = None
         for i in range(n_steps):
             last = one_step(i, timed_kernels)
+        host_issue[0] = (time.perf_counter() - t0) / n_steps * 1e3      # host time to ENQUEUE a step (no device wait inside)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -291,6 +301,7 @@ def main():
     ops.PROFILE = {}               # every profiled launch of the timed steps carries its own start/stop hipEvents
     model.comm_events = {} if (world > 1 or rehearse) else None
     dt, loss = timed_region(args.steps, True)
+    host_issue_ms = host_issue[0]
     loss_val = float(loss)
     assert loss_val == loss_val, "loss is NaN"
     prof, ops.PROFILE = ops.PROFILE or {}, None
@@ -315,7 +326,9 @@ def main():
             "backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(), "one_device_rehearsal": bool(args.one_device),
             "single_rank_rehearsal": bool(rehearse),
             "launcher": os.environ.get("CP2_BENCH_LAUNCHER", "external"), "shuffle_exchange": args.shuffle_exchange,
-            "overlap_key_branch": args.overlap, "ddp_bucket_mb": args.bucket_mb or builder.DDP_BUCKET_MB,
+            "overlap_key_branch": args.overlap, "grad_sync": args.grad_sync,
+            "ddp_bucket_mb": args.bucket_mb or builder.DDP_BUCKET_MB,
+            "grad_buckets": len(wrapped.reducer.buckets) if args.grad_sync == "flat" else None,
             "ms_per_step": {   # stream time between the events around each exchange step (it includes waiting for peers)
                 "c1_image_exchange": ev_ms("c1_image_exchange"), "c3_key_unshuffle": ev_ms("c3_key_unshuffle"),
                 "c4_key_gather_enqueue": ev_ms("c4_key_gather_enqueue"),
@@ -390,7 +403,8 @@ def main():
     out = {
         "metric": "pretrain images/sec (whole node), ResNet-50 CP2 224^2, queue=65536",
         "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "host_issue_ms_per_step": round(host_issue_ms, 3),
+        "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16" if amp is not None else "f32", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: ResNet-50 + FCN(contrast) head OS16, {hw}x{hw} copy-paste pairs, "
                                f"queue={args.queue}, {b} img/GPU, encoders bf16 autocast channels-last, loss kernels fp32 (f32 MFMA), "

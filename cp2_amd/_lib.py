@@ -54,6 +54,7 @@ SIGNATURES = {
     "cp2_blur_to_tensor": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "cp2_erase_rect": [_P, _P, c_int, c_int, c_int, _P],
     "cp2_sgd_flat": [_P, _P, _P, _P, c_int, _P, _P, c_float, _P, c_float, c_float, _P],
+    "cp2_pack_grads": [_P, _P, c_int, c_int, _P, _P, c_float, _P],
     "cp2_bf16_image": [_P, _P, c_int64, _P],
     "cp2_wgrad1x1_num_splits": [c_int, c_int, c_int],
     "cp2_wgrad1x1": [_P, _P, _P, _P, c_int, c_int, c_int, _P],

@@ -330,7 +330,7 @@ class MODEL(nn.Module):
         self._flat_q_bf16 = None         # bf16 image of the query weights, written by optim.FlatSGD (enable_query_shadow)
         self._q_shadow_version = None
         self.ema_in_forward = True       # False: the caller runs _momentum_update_key_encoder() itself before forward
-        self.overlap_key_branch = None   # None: "gather" when world size > 1, off at 1; see forward_cp2
+        self.overlap_key_branch = None   # None / False: one stream (default); "gather" / True: side-stream forms, see forward_cp2
         self._side_stream = None
         self.key_forward_graph = True    # replay the (gradient-free) key encoder forward from a hipGraph after warm-up
         self._key_graph = None
@@ -467,13 +467,17 @@ class MODEL(nn.Module):
     @torch.no_grad()
     def _enqueue(self, queue, ptr, keys):
         """All-gather the keys over the ranks (C4) and write them into the queue (reference builder.py:569-607).  With
-        more than one rank both run on the side HIP stream: nothing on the main stream needs the updated queue before
+        overlap_key_branch set, both run on the side HIP stream: nothing on the main stream needs the updated queue before
         the NEXT step's loss section, which waits for `_enqueue_done` (so does anything that reads the queue from
         outside: wait_enqueue())."""
         keys = keys.contiguous()
         cur = torch.cuda.current_stream()
         if not cdist.multi() or torch.cuda.is_current_stream_capturing():
             ops.enqueue(queue, keys, ptr)
+            return
+        if not self.overlap_key_branch:                   # default: in order on the step's stream (see forward_cp2)
+            with self._comm("c4_key_gather_enqueue"):
+                ops.enqueue(queue, concat_all_gather(keys), ptr)
             return
         side = self._key_stream()
         side.wait_stream(cur)
@@ -583,7 +587,8 @@ class MODEL(nn.Module):
                 # one rank: permutation and its inverse on the host (the global torch RNG, as builder.py:618), one copy --
                 # a device argsort is a sort kernel plus four helper launches per step
                 host = torch.randperm(b)
-                both = torch.stack([host, torch.argsort(host)]).to(img_a.device, non_blocking=True)
+                both = torch.stack([host, torch.argsort(host)])
+                both = both.pin_memory().to(img_a.device, non_blocking=True) if img_a.is_cuda else both
                 idx_shuffle, idx_unshuffle = both[0], both[1]
             else:
                 idx_unshuffle = torch.argsort(idx_shuffle)
@@ -614,16 +619,18 @@ class MODEL(nn.Module):
 
         # The key branch (EMA -> shuffle-BN exchange -> key encoder -> un-shuffle) does not depend on the query encoder
         # (reference order builder.py:1260-1277 is serial).  overlap_key_branch:
-        #   "gather" (default when world size > 1): EMA + the image exchange run on a side HIP stream and overlap the query
-        #            forward; the key encoder itself follows on the main stream (two compute-heavy branches interleaved on
-        #            one GPU measured 4 % SLOWER than back to back);
-        #   True: the whole key branch on the side stream;   False (default at world size 1): everything in order.
+        #   False / None (default at every world size): everything in order on ONE stream.  Measured with the step's
+        #            collectives running over RCCL with one rank (bench.py --rehearse-collectives): 13.73 ms per step in
+        #            order against 15.1-15.6 ms with "gather" -- a fork / join between HIP streams costs this stack far more
+        #            than the ~0.14 ms of EMA + exchange it can hide;
+        #   "gather": EMA + the image exchange (and the key all-gather + enqueue) on a side HIP stream, overlapping the query
+        #            forward; the key encoder itself follows on the main stream;
+        #   True: the whole key branch on the side stream (two compute-heavy branches interleaved on one GPU: 4 % slower
+        #            still, round 1).
         self.flatten_parameters()        # on the main stream, before the fork: it re-homes the query parameters too
         self._refresh_query_shadow()
         cur = torch.cuda.current_stream()
-        mode = self.overlap_key_branch
-        if mode is None:
-            mode = "gather" if multi else False
+        mode = self.overlap_key_branch or False
         side = self._key_stream() if mode else cur
         if side is not cur:
             side.wait_stream(cur)

@@ -126,3 +126,60 @@ CP2_API int cp2_sgd_flat(float* p, float* momentum_buf, void* p_bf16, const void
     }
     return cp2_launch_status();
 }
+
+// Gradient packing for the averaging over ranks (reference main.py:456-460 wraps the model in DistributedDataParallel,
+// whose reducer copies every parameter's gradient into a bucket with one small kernel each -- 161 launches per step on
+// ResNet-50).  Here the gradients of a contiguous range of parameter tensors go into their slots of ONE flat gradient
+// buffer (the layout of the flat parameter buffer) in a single launch, already scaled by 1 / world size as DDP's bucket
+// copies are (g * float(1/W) before the sum; exact for the power-of-two world sizes of a node), and the flat range is then
+// all-reduced in place.  Same block table as cp2_sgd_flat.  A tensor without gradient: slot zeroed.
+// HBM-bound: 8 B per parameter (read g, write flat).
+struct PackArgs {
+    float* flat;
+    const int4* blk_tab;
+    int blk0, t0;
+    float scale;
+    const float* grads[CP2_SGD_MAX_TENSORS];
+};
+
+__global__ __launch_bounds__(kSgdThreads) void pack_grads_kernel(PackArgs a) {
+    const int4 e = a.blk_tab[a.blk0 + blockIdx.x];
+    const float* __restrict__ g = a.grads[e.x - a.t0];
+    const int i = threadIdx.x * 4;
+    if (i >= e.w) return;
+    float* d = a.flat + e.y + i;
+    if (g == nullptr) {
+        for (int j = 0; j < min(4, e.w - i); ++j) d[j] = 0.f;
+        return;
+    }
+    g += e.z + i;
+    if (g == d && a.scale == 1.f) return;              // the gradient already lives in its slot
+    if (i + 4 <= e.w && (reinterpret_cast<uintptr_t>(g) & 15u) == 0) {
+        sgd_f4 v = __builtin_nontemporal_load(reinterpret_cast<const sgd_f4*>(g));
+        if (a.scale != 1.f) { v.x = __fmul_rn(v.x, a.scale); v.y = __fmul_rn(v.y, a.scale); v.z = __fmul_rn(v.z, a.scale); v.w = __fmul_rn(v.w, a.scale); }
+        *reinterpret_cast<sgd_f4*>(d) = v;
+    } else {
+        for (int j = 0; j < min(4, e.w - i); ++j) d[j] = a.scale != 1.f ? __fmul_rn(g[j], a.scale) : g[j];
+    }
+}
+
+CP2_API int cp2_pack_grads(float* flat_grad, const void* const* grads, int t_begin, int t_end, const int32_t* blk_tab,
+                           const int32_t* tensor_first_block, float scale, void* stream) {
+    if (!flat_grad || !grads || !blk_tab || !tensor_first_block) return CP2_ERR_NULL;
+    if (t_begin < 0 || t_end <= t_begin) return CP2_ERR_SHAPE;
+    if (!cp2_aligned16(flat_grad) || !cp2_aligned16(blk_tab)) return CP2_ERR_ALIGN;
+    hipStream_t s = cp2_stream(stream);
+    for (int t0 = t_begin; t0 < t_end; t0 += CP2_SGD_MAX_TENSORS) {
+        const int t1 = t0 + CP2_SGD_MAX_TENSORS < t_end ? t0 + CP2_SGD_MAX_TENSORS : t_end;
+        PackArgs a;
+        a.flat = flat_grad; a.blk_tab = reinterpret_cast<const int4*>(blk_tab);
+        a.blk0 = tensor_first_block[t0]; a.t0 = t0; a.scale = scale;
+        for (int t = t0; t < t1; ++t) a.grads[t - t0] = static_cast<const float*>(grads[t]);
+        for (int t = t1 - t0; t < CP2_SGD_MAX_TENSORS; ++t) a.grads[t] = nullptr;
+        const int nblk = tensor_first_block[t1] - tensor_first_block[t0];
+        if (nblk < 0) return CP2_ERR_SHAPE;
+        if (nblk == 0) continue;
+        hipLaunchKernelGGL(pack_grads_kernel, dim3((unsigned)nblk), dim3(kSgdThreads), 0, s, a);
+    }
+    return cp2_launch_status();
+}

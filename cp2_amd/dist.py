@@ -149,7 +149,13 @@ class ShufflePlan:
     def device_tables(self, device):
         """(send_rows, place, back_rows, back_place) as int64 device tensors: one small host-to-device copy."""
         if self._dev is None or self._dev[0].device != torch.device(device):
-            packed = torch.stack([self.send_rows, self.place, self.back_rows, self.back_place]).to(device)
+            packed = torch.stack([self.send_rows, self.place, self.back_rows, self.back_place])
+            if torch.device(device).type == "cuda":
+                # page-locked source + non_blocking: a blocking copy would make the host wait for everything queued on the
+                # stream (the previous step's backward pass and update) before it can enqueue this step
+                packed = packed.pin_memory().to(device, non_blocking=True)
+            else:
+                packed = packed.to(device)
             self._dev = tuple(packed[i] for i in range(4))
         return self._dev
 

@@ -28,6 +28,7 @@ import torch.multiprocessing as mp
 from torch.nn.parallel import DistributedDataParallel
 
 from . import builder, synthetic
+from .ddp import FlatDDP
 from .config import Config
 from .engine import TrainStep
 from .pretrain_types import PretrainType
@@ -106,6 +107,8 @@ def get_args(argv=None):
     p.add_argument("--steps_per_epoch", default=100, type=int, help="with --synthetic: steps per epoch")
     p.add_argument("--amp", default="bf16", choices=["none", "bf16"], help="encoder autocast dtype")
     p.add_argument("--no_channels_last", action="store_true")
+    p.add_argument("--grad_sync", default="flat", choices=["flat", "ddp"],
+                   help="world size > 1: gradient averaging by cp2_amd.ddp.FlatDDP (default) or torch's DistributedDataParallel")
     # fmt: on
     args = p.parse_args(argv)
     args.pretrain_type = PretrainType[args.pretrain_type]
@@ -197,8 +200,11 @@ def main_worker(rank, args):
         # broadcast of the reference's default DDP is dropped; every parameter the chosen
         # path never uses is frozen in builder.MODEL (conv_seg on the contrast path, the segmentation head
         # and the unselected neck heads for DENSECL / PROPOSED_V2), so no unused-parameter search either.
-        wrapped = DistributedDataParallel(model, device_ids=[local], output_device=local, broadcast_buffers=False,
-                                          gradient_as_bucket_view=True)
+        if args.grad_sync == "flat":     # one pack launch + one all-reduce per bucket of the flat gradient buffer (ddp.py)
+            wrapped = FlatDDP(model)
+        else:
+            wrapped = DistributedDataParallel(model, device_ids=[local], output_device=local, broadcast_buffers=False,
+                                              gradient_as_bucket_view=True, bucket_cap_mb=builder.DDP_BUCKET_MB)
     optimizer = make_optimizer([p for p in model.parameters()], args, device, capturable=False, model=model)
     if args.resume and os.path.isfile(args.resume):
         ck = torch.load(args.resume, map_location=device)

@@ -351,6 +351,17 @@ def sgd_flat(plan: SgdFlatPlan, p: torch.Tensor, buf: torch.Tensor, p_bf16: Opti
     _lib.check(rc, "cp2_sgd_flat")
 
 
+def pack_grads(plan: SgdFlatPlan, flat_grad: torch.Tensor, grad_ptrs, t_begin: int, t_end: int, scale: float) -> None:
+    """flat_grad[slot of tensor t] = scale * gradient t for t in [t_begin, t_end), one launch (cp2_pack_grads).
+    grad_ptrs: ctypes array of ntensors device pointers (None: the slot is zeroed)."""
+    import numpy as np
+    if not 0 <= t_begin < t_end <= plan.ntensors:
+        raise ValueError(f"pack_grads: tensor range [{t_begin}, {t_end}) outside 0..{plan.ntensors}")
+    rc = _lib.load().cp2_pack_grads(_dev(flat_grad, "flat_grad", torch.float32), grad_ptrs, t_begin, t_end,
+                                    plan.blk_tab.data_ptr(), plan.first, float(np.float32(scale)), _stream())
+    _lib.check(rc, "cp2_pack_grads")
+
+
 class EmaMultiPlan:
     """Device tables for cp2_ema_multi over two parameter lists (built once, reused every step)."""
 

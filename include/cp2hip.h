@@ -320,6 +320,12 @@ int cp2_blur_to_tensor(const uint32_t* img_rgbx, const int32_t* params, const in
 int cp2_sgd_flat(float* p, float* momentum_buf, void* p_bf16, const void* const* grads, int ntensors,
                  const int32_t* blk_tab, const int32_t* tensor_first_block, float lr, const float* lr_dev,
                  float momentum, float weight_decay, void* stream);
+/* Gradient averaging over the ranks, the local half (reference main.py:456-460: DistributedDataParallel; its reducer
+ * copies each parameter's gradient into a bucket, one launch per parameter).  Writes scale * grads[t] into tensor t's slot
+ * of flat_grad (the layout of the flat parameter buffer, tables as cp2_sgd_flat) for t in [t_begin, t_end) in one launch;
+ * grads[t] == NULL zeroes the slot.  scale = 1 / world size: the flat range is then summed over the ranks in place. */
+int cp2_pack_grads(float* flat_grad, const void* const* grads, int t_begin, int t_end, const int32_t* blk_tab,
+                   const int32_t* tensor_first_block, float scale, void* stream);
 /* dst[i] = bf16(src[i]) (round to nearest even) for a flat buffer, n % 4 == 0: rebuilds the bf16 weight image. */
 int cp2_bf16_image(const float* src, void* dst, int64_t n, void* stream);
 

@@ -79,9 +79,10 @@ def test_bench_two_ranks_one_device_without_a_launcher(exchange):
     c = out["comm"]
     assert c["backend"] == "gloo" and c["rccl_ranks"] == 2 and c["launcher"] == "self" and c["shuffle_exchange"] == exchange
     ms = c["ms_per_step"]
-    for k in ("c1_image_exchange", "c3_key_unshuffle", "c4_key_gather_enqueue", "key_branch_wait_exposed",
-              "step_without_grad_allreduce", "ddp_allreduce_exposed"):
+    for k in ("c1_image_exchange", "c3_key_unshuffle", "c4_key_gather_enqueue", "step_without_grad_allreduce", "ddp_allreduce_exposed"):
         assert ms[k] is not None, k
+    assert ms["key_branch_wait_exposed"] is None           # default: one stream, nothing to wait for
+    assert c["grad_sync"] == "flat" and c["grad_buckets"] >= 1
     assert ms["c1_image_exchange"] > 0 and ms["c3_key_unshuffle"] > 0 and ms["c4_key_gather_enqueue"] > 0
     by = c["bytes_received_per_rank_per_step"]
     row = 3 * 64 * 64 * 2                                  # composed images travel in bf16 under bf16 autocast

@@ -64,15 +64,62 @@ def _worker(rank, world, port, out_dir, mode="torch-sgd"):
             return
         if mode == "flat-gather-allgather":
             model.shuffle_exchange = "all_gather"
-        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], output_device=0, broadcast_buffers=False,
-                                                        gradient_as_bucket_view=True)
+        if mode in ("flat-inline", "densecl-v2", "flatddp-vs-ddp"):     # cp2_amd.ddp.FlatDDP: what main.py / bench.py use by default
+            from cp2_amd.ddp import FlatDDP
+            ddp = FlatDDP(model, bucket_mb=4)
+            assert len(ddp.reducer.buckets) >= 3
+        else:
+            ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], output_device=0, broadcast_buffers=False,
+                                                            gradient_as_bucket_view=True)
+        if mode == "flatddp-vs-ddp":
+            # what DistributedDataParallel would leave in p.grad, from the SAME backward pass (two passes differ by the decode
+            # head's dropout mask and the atomics of the weight-gradient kernels): the local gradients are recorded as the pack
+            # launch sees them, scaled by 1/2 and summed over the two ranks by the test -- equal bit for bit (two ranks: one
+            # summation order), every p.grad a view of the flat gradient buffer; no_sync() leaves the local gradient alone
+            from cp2_amd import ops
+            red, seen, pack = ddp.reducer, {}, ops.pack_grads
+
+            def spy(plan, flat, ptrs, lo, hi, scale):
+                assert scale == 0.5
+                for t in range(lo, hi):
+                    if red.params[t].requires_grad:
+                        seen[t] = red.params[t].grad.detach().clone()
+                return pack(plan, flat, ptrs, lo, hi, scale)
+            ops.pack_grads = spy
+            for step in range(2):
+                batch = synthetic.make_batch(4, 64, 64, dev, seed=100 * rank + step)
+                model.zero_grad(set_to_none=True)
+                seen.clear()
+                ddp(visualize=False, step=step, new_epoch=False, **batch).backward()
+                assert sorted(seen) == [t for t, p in enumerate(red.params) if p.requires_grad] and len(seen) > 20
+                for t, local in seen.items():
+                    want = local * 0.5
+                    dist.all_reduce(want)
+                    p = red.params[t]
+                    assert torch.equal(p.grad, want) and float(want.abs().max()) > 0, t
+                    assert p.grad.data_ptr() == red.views[t].data_ptr() and p.grad.stride() == p.stride()
+            ops.pack_grads = pack
+            assert ddp.reducer.layout_copies == 0
+            model.zero_grad(set_to_none=True)
+            with ddp.no_sync():
+                ddp(visualize=False, step=9, new_epoch=False, **batch).backward()
+            g = model.encoder_q.backbone.conv1.weight.grad
+            assert g.data_ptr() != ddp.reducer.views[0].data_ptr()
+            gathered = [torch.empty_like(g) for _ in range(world)]
+            dist.all_gather(gathered, g.contiguous())
+            assert not torch.equal(gathered[0], gathered[1])                  # local gradients: different data on each rank
+            torch.save({"ok": True}, os.path.join(out_dir, f"r{rank}.pt"))
+            dist.barrier()
+            return
         steps = 3
         if mode in ("torch-sgd", "densecl", "densecl-v2"):
             opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=0.01, momentum=0.9, weight_decay=1e-4)
         else:        # the bench / main.py configuration: FlatSGD, enough steps for the key-forward hipGraph to be replayed
             from cp2_amd.optim import FlatSGD
             opt = FlatSGD(ddp, 0.01, momentum=0.9, weight_decay=1e-4)
-            model.overlap_key_branch = {"flat-gather": None, "flat-gather-allgather": None, "flat-branch": True}[mode]
+            # "flat-inline": the default (everything in order on one stream); the side-stream forms stay covered
+            model.overlap_key_branch = {"flat-inline": None, "flat-gather": "gather", "flat-gather-allgather": "gather",
+                                        "flat-branch": True}[mode]
             steps = 6
         b = 6
         for step in range(steps):
@@ -82,7 +129,7 @@ def _worker(rank, world, port, out_dir, mode="torch-sgd"):
             loss.backward()
             opt.step()
             assert torch.isfinite(loss)
-        assert densecl or model._side_stream is not None                          # key branch ran on the side stream
+        assert (model._side_stream is not None) == (mode in ("flat-gather", "flat-gather-allgather", "flat-branch"))
         if mode.startswith("flat"):
             assert model._key_graph is not None and any(e["graph"] is not None for e in model._key_graph.entries.values())
         torch.cuda.synchronize()
@@ -96,7 +143,7 @@ def _worker(rank, world, port, out_dir, mode="torch-sgd"):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("mode", ["torch-sgd", "flat-gather", "flat-gather-allgather", "flat-branch", "densecl", "densecl-v2"])
+@pytest.mark.parametrize("mode", ["torch-sgd", "flat-inline", "flat-gather", "flat-gather-allgather", "flat-branch", "densecl", "densecl-v2"])
 def test_two_ranks_one_device_gloo(tmp_path, mode):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), mode), nprocs=world, join=True)
@@ -105,6 +152,12 @@ def test_two_ranks_one_device_gloo(tmp_path, mode):
     assert torch.equal(r0["queue"], r1["queue"])                  # identical enqueue on every rank, in rank order
     assert torch.equal(r0["grad"], r1["grad"]) and float(r0["grad"].abs().max()) > 0   # DDP-averaged gradients
     assert torch.equal(r0["w"], r1["w"]) and torch.equal(r0["k"], r1["k"])             # replicas stay in lock-step
+
+
+@pytest.mark.timeout(300)
+def test_flat_ddp_gradients_are_the_rank_average_of_this_backward_pass(tmp_path):
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), "flatddp-vs-ddp"), nprocs=2, join=True)
+    assert torch.load(tmp_path / "r0.pt")["ok"] and torch.load(tmp_path / "r1.pt")["ok"]
 
 
 @pytest.mark.timeout(300)

@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, port, out_dir):
+def _worker(rank, port, out_dir, grad_sync):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import sys
     sys.path.insert(0, ROOT)
@@ -56,10 +56,14 @@ def _worker(rank, port, out_dir):
                               amp_dtype=torch.bfloat16, channels_last=True).to(dev).train()
         model.encoder_q.to(memory_format=torch.channels_last)
         model.encoder_k.to(memory_format=torch.channels_last)
-        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], output_device=0, broadcast_buffers=False,
-                                                        gradient_as_bucket_view=True)
+        if grad_sync == "flat":                               # the default of main.py / bench.py
+            from cp2_amd.ddp import FlatDDP
+            ddp = FlatDDP(model, bucket_mb=4)
+        else:
+            ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], output_device=0, broadcast_buffers=False,
+                                                            gradient_as_bucket_view=True)
         opt = FlatSGD(ddp, 0.01, momentum=0.9, weight_decay=1e-4)
-        assert model.overlap_key_branch is None               # -> "gather", what world size > 1 selects
+        assert model.overlap_key_branch is None               # -> one stream, what every world size selects by default
         losses = []
         for step in range(4):
             batch = synthetic.make_batch(6, 64, 64, dev, seed=step)
@@ -70,13 +74,30 @@ def _worker(rank, port, out_dir):
             losses.append(float(loss))
         torch.cuda.synchronize()
         assert all(l == l for l in losses) and int(model.queue_ptr) == 24
-        assert model._side_stream is not None
+        assert model._side_stream is None                     # default: no side stream
+        if grad_sync == "flat":                               # every gradient went through pack + RCCL all_reduce into the flat buffer
+            red = ddp.reducer
+            assert len(red.buckets) >= 3 and red.layout_copies == 0
+            for i, p in enumerate(red.params):
+                assert not p.requires_grad or p.grad.data_ptr() == red.views[i].data_ptr()
+            assert float(red.flat.abs().sum()) > 0
+        model.overlap_key_branch = "gather"                   # the side-stream form stays available: two more steps through it
+        for step in range(4, 6):
+            batch = synthetic.make_batch(6, 64, 64, dev, seed=step)
+            loss = ddp(visualize=False, step=step, new_epoch=False, **batch)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        assert all(l == l for l in losses) and int(model.queue_ptr) == 36 and model._side_stream is not None
         torch.save({"losses": losses}, os.path.join(out_dir, "nccl.pt"))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-def test_single_rank_rccl_path(tmp_path):
-    mp.spawn(_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
-    assert len(torch.load(tmp_path / "nccl.pt")["losses"]) == 4
+@pytest.mark.parametrize("grad_sync", ["flat", "ddp"])
+def test_single_rank_rccl_path(tmp_path, grad_sync):
+    mp.spawn(_worker, args=(_free_port(), str(tmp_path), grad_sync), nprocs=1, join=True)
+    assert len(torch.load(tmp_path / "nccl.pt")["losses"]) == 6

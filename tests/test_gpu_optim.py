@@ -139,3 +139,37 @@ def test_training_step_with_flat_sgd_matches_torch_sgd_step():
     # steps within the drift two identical eager runs show.
     assert abs(losses[0][0] - losses[1][0]) <= 2e-3 and abs(losses[0][1] - losses[1][1]) <= 2e-2, losses
     assert all(abs(a - b) < 1.5e-1 for a, b in zip(*losses)), losses
+
+
+def test_pack_grads_writes_scaled_gradients_into_their_slots():
+    """cp2_pack_grads (the local half of ddp.FlatDDP): tensor ranges, ragged sizes, unaligned gradient addresses, a
+    missing gradient (slot zeroed), scale 1 (plain copy) and 1/W -- bit for bit against g * float32(scale)."""
+    from cp2_amd import ops
+    torch.manual_seed(3)
+    numels = [9408, 64, 1, 4097, 513, 36864, 7, 1000]
+    offs, total = [], 0
+    for n in numels:
+        offs.append(total)
+        total += (n + 63) // 64 * 64
+    plan = ops.SgdFlatPlan(offs, numels, DEV)
+    import ctypes
+    for scale in (1.0, 0.5, 1.0 / 3.0):
+        pool = torch.randn(sum(numels) + 64, device=DEV)
+        grads, at = [], 1                                   # start one float in: the 16-byte fast path must not be assumed
+        for n in numels:
+            grads.append(pool[at:at + n])
+            at += n
+        grads[2] = None
+        ptrs = (ctypes.c_void_p * len(numels))(*[None if g is None else g.data_ptr() for g in grads])
+        flat = torch.full((total,), 7.0, device=DEV)
+        ops.pack_grads(plan, flat, ptrs, 3, 8, scale)       # the bucket that completes first: the last tensors
+        assert torch.equal(flat[:offs[3]], torch.full((offs[3],), 7.0, device=DEV))
+        ops.pack_grads(plan, flat, ptrs, 0, 3, scale)
+        s32 = torch.tensor(scale, dtype=torch.float32, device=DEV)
+        for t, (g, o, n) in enumerate(zip(grads, offs, numels)):
+            want = torch.zeros(n, device=DEV) if g is None else g * s32
+            assert torch.equal(flat[o:o + n], want), (scale, t)
+            pad = (n + 63) // 64 * 64 - n
+            assert torch.equal(flat[o + n:o + n + pad], torch.full((pad,), 7.0, device=DEV))      # slot padding untouched
+    with pytest.raises(ValueError):
+        ops.pack_grads(plan, flat, ptrs, 4, 4, 1.0)
