@@ -32,5 +32,7 @@ def load():
                   ctypes.cast(lib.cp2_wgrad1x1_num_splits, ctypes.c_void_p).value)
     ext.set_wgrad_conv(ctypes.cast(lib.cp2_wgrad_conv, ctypes.c_void_p).value,
                        ctypes.cast(lib.cp2_wgrad_conv_num_splits, ctypes.c_void_p).value)
+    ext.set_bn(ctypes.cast(lib.cp2_bn_num_partials, ctypes.c_void_p).value, ctypes.cast(lib.cp2_bn_fwd, ctypes.c_void_p).value,
+               ctypes.cast(lib.cp2_bn_bwd, ctypes.c_void_p).value)
     _ext = ext
     return _ext

@@ -194,9 +194,89 @@ at::Tensor conv1x1(const at::Tensor& x, const at::Tensor& weight, const at::Tens
 
 }  // namespace
 
+// Fused training-mode BatchNorm (+ residual) (+ ReLU) on channels-last bf16 activations: cp2_bn_fwd / cp2_bn_bwd of
+// libcp2hip.so (csrc/bn.hip).  The Python node (encoder._FusedBNFn + ops.bn_fwd / bn_bwd) costs ~21 us of interpreter time
+// per forward call and about as much per backward call; the ResNet-50 step makes 53 + 53 of them on the query encoder
+// (tools/host_profile.py: 1.2 ms of the 4.6 ms the host needs to enqueue the query forward).  Workspace layout as ops.bn_fwd:
+// one fp32 [2G + 4, C] block = partials | scale, shift | mean, invstd; the last two rows are what backward needs.
+typedef int (*bn_partials_fn_t)(int, int);
+typedef int (*bn_fwd_fn_t)(const void*, const void*, const float*, const float*, float*, float*, float, float, int, void*, float*,
+                           float*, float*, float*, int, int, void*);
+typedef int (*bn_bwd_fn_t)(const void*, const void*, const void*, const float*, const float*, const float*, int, void*, void*,
+                           float*, float*, float*, float*, int, int, void*);
+bn_partials_fn_t g_bn_partials = nullptr;
+bn_fwd_fn_t g_bn_fwd = nullptr;
+bn_bwd_fn_t g_bn_bwd = nullptr;
+
+void set_bn(int64_t partials_fn, int64_t fwd_fn, int64_t bwd_fn) {
+    g_bn_partials = reinterpret_cast<bn_partials_fn_t>(partials_fn);
+    g_bn_fwd = reinterpret_cast<bn_fwd_fn_t>(fwd_fn);
+    g_bn_bwd = reinterpret_cast<bn_bwd_fn_t>(bwd_fn);
+}
+
+struct FusedBNFn : public torch::autograd::Function<FusedBNFn> {
+    static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& x, const at::Tensor& weight,
+                              const at::Tensor& bias, const c10::optional<at::Tensor>& residual, at::Tensor running_mean,
+                              at::Tensor running_var, double momentum, double eps, bool relu) {
+        TORCH_CHECK(g_bn_fwd != nullptr, "fused_bn: set_bn() has not been called");
+        const int64_t N = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
+        const int M = (int)(N * H * W);
+        const int G = g_bn_partials(M, (int)C);
+        TORCH_CHECK(G >= 1, "cp2_bn_num_partials failed: ", G);
+        const bool has_res = residual.has_value() && residual->defined();
+        at::Tensor y = at::empty_like(x);
+        at::Tensor ws = at::empty({2 * (int64_t)G + 4, C}, x.options().dtype(at::kFloat));
+        float* base = ws.data_ptr<float>();
+        const int rc = g_bn_fwd(x.data_ptr(), has_res ? residual->data_ptr() : nullptr, weight.data_ptr<float>(), bias.data_ptr<float>(),
+                                running_mean.data_ptr<float>(), running_var.data_ptr<float>(), (float)momentum, (float)eps, relu ? 1 : 0,
+                                y.data_ptr(), base + (2 * (int64_t)G + 2) * C, base + (2 * (int64_t)G + 3) * C, base,
+                                base + 2 * (int64_t)G * C, M, (int)C, c10::hip::getCurrentHIPStream().stream());
+        TORCH_CHECK(rc == 0, "cp2_bn_fwd failed: ", rc);
+        ctx->save_for_backward({x, relu ? y : at::Tensor(), weight, ws.narrow(0, 2 * (int64_t)G + 2, 2)});
+        ctx->saved_data["relu"] = relu;
+        ctx->saved_data["has_res"] = has_res;
+        ctx->saved_data["G"] = (int64_t)G;
+        return y;
+    }
+
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grads) {
+        const auto saved = ctx->get_saved_variables();
+        const at::Tensor& x = saved[0];
+        const at::Tensor& y = saved[1];
+        const at::Tensor& weight = saved[2];
+        const at::Tensor& stats = saved[3];
+        const bool relu = ctx->saved_data["relu"].toBool(), has_res = ctx->saved_data["has_res"].toBool();
+        const int64_t G = ctx->saved_data["G"].toInt();
+        const int64_t N = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
+        const int M = (int)(N * H * W);
+        at::Tensor dy = grads[0];
+        if (dy.scalar_type() != at::kBFloat16 || !dy.is_contiguous(at::MemoryFormat::ChannelsLast))
+            dy = dy.to(at::kBFloat16).contiguous(at::MemoryFormat::ChannelsLast);
+        at::Tensor dx = at::empty_like(x);
+        at::Tensor dres;
+        if (has_res && relu) dres = at::empty_like(x);
+        at::Tensor ws = at::empty({2 * G + 5, C}, x.options().dtype(at::kFloat));       // partials | coef[3] | dgamma, dbeta
+        float* base = ws.data_ptr<float>();
+        const float* sp = stats.data_ptr<float>();
+        const int rc = g_bn_bwd(x.data_ptr(), dy.data_ptr(), relu ? y.data_ptr() : nullptr, weight.data_ptr<float>(), sp, sp + C,
+                                relu ? 1 : 0, dx.data_ptr(), dres.defined() ? dres.data_ptr() : nullptr, base + (2 * G + 3) * C,
+                                base + (2 * G + 4) * C, base, base + 2 * G * C, M, (int)C, c10::hip::getCurrentHIPStream().stream());
+        TORCH_CHECK(rc == 0, "cp2_bn_bwd failed: ", rc);
+        if (has_res && !relu) dres = dy;
+        return {dx, ws[2 * G + 3], ws[2 * G + 4], dres, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+    }
+};
+
+at::Tensor fused_bn(const at::Tensor& x, const at::Tensor& weight, const at::Tensor& bias, const c10::optional<at::Tensor>& residual,
+                    at::Tensor running_mean, at::Tensor running_var, double momentum, double eps, bool relu) {
+    return FusedBNFn::apply(x, weight, bias, residual, running_mean, running_var, momentum, eps, relu);
+}
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("set_wgrad", &set_wgrad, "function pointers of cp2_wgrad1x1 / cp2_wgrad1x1_num_splits (libcp2hip.so)");
     m.def("set_wgrad_conv", &set_wgrad_conv, "function pointers of cp2_wgrad_conv / cp2_wgrad_conv_num_splits (libcp2hip.so)");
+    m.def("set_bn", &set_bn, "function pointers of cp2_bn_num_partials / cp2_bn_fwd / cp2_bn_bwd (libcp2hip.so)");
+    m.def("fused_bn", &fused_bn);
     m.def("conv_kxk", &conv_kxk);
     m.def("shadow_weight", &shadow_weight);
     m.def("conv1x1", &conv1x1);

@@ -56,6 +56,7 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
     matters when momentum is None, which is never fused)."""
 
     fused = True            # class-wide switch (bench.py --fused-bn off for A/B)
+    cpp_node = True         # autograd node from csrc_torch/autograd_ext.cpp when built (else the Python node below)
 
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
@@ -67,6 +68,10 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
                 and self.weight.dtype == torch.float32 and _bn_ops.bn_supported(x)
                 and (residual is None or (residual.shape == x.shape and _bn_ops.bn_supported(residual)))):
             self._pending_batches += 1
+            ext = _cext.load() if FusedBatchNorm2d.cpp_node else None
+            if ext is not None:      # the same node in C++: ~20 us less interpreter time per call and direction
+                return ext.fused_bn(x, self.weight, self.bias, residual, self.running_mean, self.running_var,
+                                    self.momentum, self.eps, relu)
             return _FusedBNFn.apply(x, self.weight, self.bias, residual, self.running_mean, self.running_var,
                                     self.momentum, self.eps, relu)
         y = super().forward(x)

@@ -92,3 +92,33 @@ def test_fallback_paths_match_stock_batchnorm():
     fused.eval(); ref.eval()
     xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)   # eval mode -> stock path
     assert torch.equal(fused(xb), ref(xb))
+
+
+def test_cpp_and_python_autograd_nodes_launch_the_same_kernels():
+    """FusedBatchNorm2d.cpp_node selects the C++ autograd node (csrc_torch/autograd_ext.cpp) or its Python twin: same
+    cp2_bn_fwd / cp2_bn_bwd launches, so outputs, gradients and running statistics are bit-identical."""
+    from cp2_amd import _cext
+    if _cext.load() is None:
+        pytest.skip("C++ autograd nodes not built")
+    torch.manual_seed(5)
+    for (N, C, H, W), relu, use_res in (((8, 256, 14, 14), True, True), ((4, 64, 28, 28), True, False), ((3, 128, 7, 5), False, True)):
+        x = torch.randn(N, C, H, W, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        res = torch.randn_like(x) if use_res else None
+        up = torch.randn_like(x)
+        got = []
+        for cpp in (True, False):
+            FusedBatchNorm2d.cpp_node = cpp
+            try:
+                bn = FusedBatchNorm2d(C).to(DEV).train()
+                with torch.no_grad():
+                    bn.weight.copy_(torch.linspace(0.5, 1.5, C)); bn.bias.copy_(torch.linspace(-0.3, 0.3, C))
+                xf = x.clone().requires_grad_(True)
+                rf = res.clone().requires_grad_(True) if use_res else None
+                y = bn(xf, residual=rf, relu=relu)
+                y.backward(up)
+                got.append((y.detach(), xf.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(), bn.running_var.clone())
+                           + ((rf.grad,) if use_res else ()))
+            finally:
+                FusedBatchNorm2d.cpp_node = True
+        for a, b in zip(*got):
+            assert torch.equal(a, b)
