@@ -107,6 +107,9 @@ def get_args(argv=None):
     p.add_argument("--steps_per_epoch", default=100, type=int, help="with --synthetic: steps per epoch")
     p.add_argument("--amp", default="bf16", choices=["none", "bf16"], help="encoder autocast dtype")
     p.add_argument("--no_channels_last", action="store_true")
+    p.add_argument("--one_device", action="store_true",
+                   help="rehearsal of the multi-rank path on a one-GPU box: every rank uses cuda:0 (RCCL refuses two ranks on "
+                        "one GPU: combine with --dist-backend gloo)")
     p.add_argument("--grad_sync", default="flat", choices=["flat", "ddp"],
                    help="world size > 1: gradient averaging by cp2_amd.ddp.FlatDDP (default) or torch's DistributedDataParallel")
     # fmt: on
@@ -181,7 +184,7 @@ def main_worker(rank, args):
     if not torch.cuda.is_available():
         raise RuntimeError("cp2_amd.main needs a GPU: the CP2 hot path has no CPU implementation "
                            "(the CPU baseline lives in oracle/ and is driven by bench.py)")
-    local = int(os.environ.get("LOCAL_RANK", rank))
+    local = 0 if args.one_device else int(os.environ.get("LOCAL_RANK", rank))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     torch.manual_seed(args.seed)

@@ -62,3 +62,37 @@ def test_main_cli_tensor_dataset_on_device_augmentation(tmp_path):
     assert "Epoch: [1][5/6]" in res.stdout                       # 48 images / batch 8 = 6 steps per epoch
     ck = torch.load(tmp_path / "d" / "checkpoint.ckpt", map_location="cpu", weights_only=False)
     assert ck["epoch"] == 2 and ck["pretrain_type"] == "PROPOSED" and int(ck["state_dict"]["module.queue_ptr"]) == (12 * 8) % 256
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("grad_sync", ["flat", "ddp"])
+def test_main_cli_two_ranks_one_device_and_resume(tmp_path, grad_sync):
+    """`cp2_amd.main --world-size 2` (reference main.py:732 spawns its ranks the same way) as a rehearsal on one GPU over
+    gloo: gradient averaging by ddp.FlatDDP (default) or torch DDP, checkpoint with the reference's "module." keys written by
+    rank 0, then a second run resumes from it for one more epoch."""
+    base = [sys.executable, "-m", "cp2_amd.main", "--config", os.path.join(ROOT, "configs", "config_pretrain_r18.py"),
+            "--log_dir", str(tmp_path), "--synthetic", "--pretrain_from_scratch", "--queue_size", "256",
+            "--img_height", "64", "--img_width", "64", "-b", "8", "--steps_per_epoch", "3", "--lr", "0.01",
+            "--print-freq", "1", "--world-size", "2", "--dist-backend", "gloo", "--one_device", "--grad_sync", grad_sync]
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    port = 29540 + (1 if grad_sync == "ddp" else 0)
+    res = subprocess.run(base + ["--run_id", "a", "--epochs", "2", "--dist-url", f"tcp://127.0.0.1:{port}"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=420)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert "Epoch: [1][2/3]" in res.stdout
+    ck_path = tmp_path / "a" / "checkpoint.ckpt"
+    ck = torch.load(ck_path, map_location="cpu", weights_only=False)
+    sd = ck["state_dict"]
+    assert ck["epoch"] == 2 and "module.encoder_q.backbone.conv1.weight" in sd and "module.queue" in sd
+    assert int(sd["module.queue_ptr"]) == (6 * 8) % 256                                  # both ranks' keys, every step
+    assert all(torch.isfinite(v).all() for v in sd.values() if v.dtype.is_floating_point)
+    res = subprocess.run(base + ["--run_id", "b", "--epochs", "3", "--resume", str(ck_path), "--dist-url", f"tcp://127.0.0.1:{port + 2}"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=420)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert "Epoch: [2][2/3]" in res.stdout and "Epoch: [1]" not in res.stdout
+    ck2 = torch.load(tmp_path / "b" / "checkpoint.ckpt", map_location="cpu", weights_only=False)
+    assert ck2["epoch"] == 3 and int(ck2["state_dict"]["module.queue_ptr"]) == (9 * 8) % 256
+    w0, w1 = sd["module.encoder_q.backbone.conv1.weight"], ck2["state_dict"]["module.encoder_q.backbone.conv1.weight"]
+    assert not torch.equal(w0, w1)                                                       # the resumed run kept training
