@@ -25,4 +25,17 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 200 rocprofv3 --kernel-trace --pmc $c -d /tmp/p10_$c -o e --output-format csv -- python3 $R/tools/ema_only.py > $O/r03_ema_$c.log 2>&1 || exit 1
   cp /tmp/p10_$c/e_counter_collection.csv $O/r03_ema_pmc_$c.csv
 done
+# 5. the multi-GPU plumbing with one rank over RCCL (bench.py --rehearse-collectives): launches and GPU-busy time per step with
+#    FlatDDP (default) and with torch DDP, idle gaps, and the host-side cost of enqueuing a step
+for GS in flat ddp; do
+  timeout -k 10 300 rocprofv3 --kernel-trace -d /tmp/p11_$GS -o p --output-format csv -- python3 $R/bench.py --steps 20 --warmup 8 --no-cpu-baseline --rehearse-collectives --grad-sync $GS --nosync-steps 0 > $O/rehearsal_$GS.json 2> $O/rehearsal_$GS.err || exit 1
+  python3 $R/tools/step_breakdown.py /tmp/p11_$GS/p_kernel_trace.csv 10 60 > $O/r03_rehearsal_${GS}_step_breakdown.txt
+  python3 $R/tools/step_gaps.py /tmp/p11_$GS/p_kernel_trace.csv 10 30 > $O/r03_rehearsal_${GS}_gaps.txt
+done
+timeout -k 10 300 python3 $R/tools/host_profile.py 30 50 > $O/r03_host_profile.txt 2> $O/host_profile.err || exit 1
+# 6. the bench lines themselves, outside the profiler: N = 1 and the single-rank rehearsal of the N > 1 path
+cd $R
+python3 bench.py --gpus 1 --steps 50 --warmup 10 > $O/r03_bench_n1.json 2> $O/bench_n1.err || exit 1
+python3 bench.py --gpus 1 --steps 50 --warmup 10 --no-cpu-baseline --rehearse-collectives > $O/r03_bench_rehearsal_flatddp.json 2> $O/bench_reh.err || exit 1
+python3 bench.py --gpus 1 --steps 50 --warmup 10 --no-cpu-baseline --rehearse-collectives --grad-sync ddp > $O/r03_bench_rehearsal_torchddp.json 2>> $O/bench_reh.err || exit 1
 ls -la $O
