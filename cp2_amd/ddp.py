@@ -59,8 +59,9 @@ def plan_buckets(numels: Sequence[int], bucket_elems: int, tail_elems: int = 0) 
 
 class GradReducer:
     """The bucket bookkeeping, independent of the model class: `params` in flat-buffer order, `offsets[i]` the first
-    element of parameter i's slot, `total` the buffer length.  `pack(t_begin, t_end, grads)` performs the local copy
-    (grads[i]: the gradient tensor of parameter i in its slot's element order, or None); the default is the HIP launch."""
+    element of parameter i's slot, `total` the buffer length.  `pack(t_begin, t_end, grads, reducer)` performs the local
+    copy (grads[i]: the gradient tensor of parameter i in its slot's element order, or None); the default -- and the only one
+    the package ships -- is the HIP launch; the gloo tests of the bookkeeping pass their own for CPU tensors."""
 
     def __init__(self, params: Sequence[torch.nn.Parameter], offsets: Sequence[int], total: int, bucket_mb: float = 25.0,
                  pack: Optional[Callable] = None):
@@ -163,15 +164,6 @@ class GradReducer:
                 p.grad = v
 
 
-def pack_on_host(lo: int, hi: int, grads, red: "GradReducer") -> None:
-    """The local copy written with tensor operations: for CPU tensors (gloo tests of the bookkeeping)."""
-    for t, g in zip(range(lo, hi), grads):
-        if g is None:
-            red.views[t].zero_()
-        else:
-            torch.mul(g, red.scale, out=red.views[t])
-
-
 class FlatDDP(torch.nn.Module):
     """Drop-in for DistributedDataParallel(model, ...) around builder.MODEL (reference main.py:456-460)."""
 
@@ -189,9 +181,11 @@ class FlatDDP(torch.nn.Module):
             raise ValueError(f"FlatDDP: trainable parameters outside encoder_q: {stray[:3]}")
         if broadcast_at_init and cdist.multi():
             self._broadcast_state()
-        pack = None if params[0].is_cuda else pack_on_host
+        if not params[0].is_cuda:
+            raise RuntimeError("FlatDDP: the model is on " + str(params[0].device) + "; the gradient pack kernel (cp2_pack_grads) "
+                               "runs on the GPU only")
         self.reducer = GradReducer(params, module._flat_offsets, module._flat_q.numel(),
-                                   builder.DDP_BUCKET_MB if bucket_mb is None else bucket_mb, pack=pack)
+                                   builder.DDP_BUCKET_MB if bucket_mb is None else bucket_mb)
 
     @torch.no_grad()
     def _broadcast_state(self) -> None:

@@ -1,7 +1,7 @@
 """CPU, gloo: the bucket bookkeeping of cp2_amd.ddp.GradReducer (the replacement for DistributedDataParallel's reducer,
 reference main.py:456-460) against torch's DistributedDataParallel on the same small network: averaged gradients equal
 bit for bit with two ranks (to rounding of the summation order with four), no_sync() accumulates locally, a parameter without gradient is reported.  The
-local copy is played by tensor operations here (ddp.pack_on_host); the HIP launch is covered by tests/test_gpu_ddp.py."""
+local copy is played by tensor operations here (pack_on_host below); the HIP launch is covered by tests/test_gpu_ddp.py."""
 import os
 import socket
 
@@ -19,6 +19,16 @@ def _free_port():
     p = s.getsockname()[1]
     s.close()
     return p
+
+
+def pack_on_host(lo, hi, grads, red):
+    """The local copy of a bucket written with tensor operations, for the CPU tensors of this test (the product's is the HIP
+    launch cp2_pack_grads, checked bit for bit in tests/test_gpu_optim.py)."""
+    for t, g in zip(range(lo, hi), grads):
+        if g is None:
+            red.views[t].zero_()
+        else:
+            torch.mul(g, red.scale, out=red.views[t])
 
 
 def _net():
@@ -50,7 +60,7 @@ def _worker(rank, world, port, out_dir):
         net[2].weight.data = net[2].weight.data.contiguous(memory_format=torch.channels_last)   # a [co,ci,1,1] weight: same memory
         ref = torch.nn.parallel.DistributedDataParallel(ref_net)
         params, offs, total = _flatten(net)
-        red = cddp.GradReducer(params, offs, total, bucket_mb=100 * 4 / (1 << 20), pack=cddp.pack_on_host)
+        red = cddp.GradReducer(params, offs, total, bucket_mb=100 * 4 / (1 << 20), pack=pack_on_host)
         assert len(red.buckets) >= 3 and red.buckets[0][1] == len(params) and red.buckets[-1][0] == 0
         assert sorted(t for lo, hi in red.buckets for t in range(lo, hi)) == list(range(len(params)))
         assert all(hi_f - lo_f >= 1 for lo_f, hi_f in red.ranges) and red.ranges[0][1] == total and red.ranges[-1][0] == 0
