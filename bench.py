@@ -14,8 +14,10 @@ queue 65536, 32 images per GPU (weak scaling: 32 per GPU at every N).  Prints ON
 
 With N > 1 the line also carries `comm`: backend, rccl_ranks, and per-step times of every exchange step measured with
 events on the stream it runs on -- C1 shuffle-BN image exchange, C3 key un-shuffle, C4 key all-gather + enqueue, the
-main stream's wait for the side stream, and the exposed (non-overlapped) part of DDP's gradient all-reduce (step time
-minus the step time of a few extra steps under no_sync()) -- so that the first multi-GPU run explains its own scaling.
+main stream's wait for the side stream when --overlap selects one, and the exposed (non-overlapped) part of the gradient
+averaging (step time minus the step time of a few extra steps under no_sync()) -- so that the first multi-GPU run explains
+its own scaling.  `host_issue_ms_per_step` is the time the CPU needs to enqueue a step: when it approaches `ms_per_step`
+the run was host-bound, not GPU-bound.  `--rehearse-collectives` runs the N > 1 code path with one rank over RCCL.
 """
 import argparse
 import json

@@ -550,7 +550,7 @@ class MODEL(nn.Module):
 
     # ------------------------------------------------------------------ dispatch
     def forward(self, **kwargs):
-        self.wait_enqueue()                     # the previous step's queue update (side stream when world size > 1)
+        self.wait_enqueue()                     # the previous step's queue update (when it ran on the side stream)
         if self._flat_q_bf16 is not None:       # bf16 weight image in use: rebuild it if a parameter changed elsewhere
             self.flatten_parameters()
             self._refresh_query_shadow()
