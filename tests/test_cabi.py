@@ -85,3 +85,20 @@ def test_cpp_autograd_nodes_are_built_and_importable():
     ext = _cext.load()
     assert ext is not None, "run `python -c 'import __graft_entry__ as g; g.build()'` first"
     assert all(hasattr(ext, n) for n in ("conv1x1", "shadow_weight", "set_wgrad"))
+
+
+def test_pack_grads_and_fused_bn_node_entry_points():
+    """cp2_pack_grads rejects bad arguments before anything is launched (host-side checks only: safe without a GPU), and the
+    C++ extension exports the fused-BN node next to the convolution nodes."""
+    import ctypes
+    lib = _lib.load()
+    ptrs = (ctypes.c_void_p * 2)()
+    first = (ctypes.c_int32 * 3)(0, 1, 2)
+    assert lib.cp2_pack_grads(None, ptrs, 0, 2, 64, first, 1.0, None) == -1                # null flat buffer
+    assert lib.cp2_pack_grads(64, None, 0, 2, 64, first, 1.0, None) == -1
+    assert lib.cp2_pack_grads(64, ptrs, 2, 2, 64, first, 1.0, None) == -2                  # empty tensor range
+    assert lib.cp2_pack_grads(64, ptrs, -1, 2, 64, first, 1.0, None) == -2
+    assert lib.cp2_pack_grads(68, ptrs, 0, 2, 64, first, 1.0, None) == -4                  # flat buffer not 16-byte aligned
+    from cp2_amd import _cext
+    ext = _cext.load()
+    assert ext is not None and hasattr(ext, "fused_bn") and hasattr(ext, "set_bn")
