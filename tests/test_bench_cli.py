@@ -87,3 +87,20 @@ def test_bench_two_ranks_one_device_without_a_launcher(exchange):
     by = c["bytes_received_per_rank_per_step"]
     row = 3 * 64 * 64 * 2                                  # composed images travel in bf16 under bf16 autocast
     assert by["c1_image_exchange"] == (2 * row if exchange == "all_to_all" else 4 * row)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("grad_sync", ["flat", "ddp"])
+def test_bench_single_rank_rccl_rehearsal(grad_sync):
+    """`--rehearse-collectives`: the N > 1 code path (exchange steps, gradient buckets, RCCL calls) with ONE rank on a one-GPU
+    box; the line is an N = 1 line plus the `comm` breakdown, and says so."""
+    res = _run(["--gpus", "1", "--no-cpu-baseline", "--rehearse-collectives", "--grad-sync", grad_sync, "--nosync-steps", "2"] + SMALL)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.strip()][-1])
+    c = out["comm"]
+    assert out["n_gpus"] == 1 and c["single_rank_rehearsal"] is True and c["backend"] == "nccl" and c["rccl_ranks"] == 1
+    assert c["grad_sync"] == grad_sync and (c["grad_buckets"] >= 1 if grad_sync == "flat" else c["grad_buckets"] is None)
+    ms = c["ms_per_step"]
+    assert ms["c1_image_exchange"] > 0 and ms["c3_key_unshuffle"] > 0 and ms["c4_key_gather_enqueue"] > 0
+    assert ms["step_without_grad_allreduce"] > 0 and out["host_issue_ms_per_step"] > 0
