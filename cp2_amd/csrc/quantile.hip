@@ -402,96 +402,126 @@ __global__ __launch_bounds__(QT3) void quantile_select_kernel(QuantJobs jobs) {
 // on narrow-band rows -- 70 us instead of 63-66: the passes are bound by their ~30 VALU instructions per element on the
 // one CU a row has, not by atomic conflicts.)
 constexpr int QROW_MAX = CP2_QUANTILES_ROW_MAX;
-__global__ __launch_bounds__(QT3) void quantiles_row_kernel(QuantJobs jobs) {
-    int jsel = 0;
-#pragma unroll
-    for (int j = 1; j < QJOBS; ++j) jsel += ((int)blockIdx.x >= jobs.first_row[j]) ? 1 : 0;
-    const QuantArgs& a = jobs.job[jsel];
-    extern __shared__ __attribute__((aligned(16))) unsigned char q_smem[];
-    __shared__ unsigned hist0[QB0];
-    __shared__ unsigned hist[QMAX][QB1];
-    __shared__ unsigned wtot[16];
-    __shared__ unsigned sh_prefix[QMAX], sh_k[QMAX], sh_min[QMAX], sh_next[QMAX], sh_n;
-    float* lma = reinterpret_cast<float*>(q_smem);
-    float* lmb = lma + (a.want >= 0 ? a.P : 0);
-    const int r = (int)blockIdx.x - jobs.first_row[jsel], tid = threadIdx.x, NQ = a.NQ;
-    const float* row = a.x + (int64_t)r * a.s_row;
-    const bool masked = a.want >= 0;
-    if (masked) {
-        for (int i = tid; i < a.P; i += QT3) { lma[i] = a.mask_a[(int64_t)r * a.P + i]; lmb[i] = a.mask_b[(int64_t)r * a.P + i]; }
-    }
-    for (int i = tid; i < QB0; i += QT3) hist0[i] = 0;
-    __syncthreads();
-    const bool vec = a.s_elem == 1 && ((reinterpret_cast<uintptr_t>(row) & 15u) == 0);
-    auto keep_at = [&](int x, int y, float v) -> bool {
-        if (v != v) return false;                          // nanquantile ignores NaN
-        if (!masked) return true;
-        return ((lma[x] * lmb[y]) != 0.f) == (a.want != 0);
-    };
-    // Visit every kept element of the row once: 16-byte loads when the row is contiguous, four loads in flight otherwise.
-#define CP2_Q_FOREACH(BODY)                                                                              \
-    if (vec) {                                                                                           \
-        const int n4 = (a.N + 3) >> 2;                                                                   \
-        for (int j4 = tid; j4 < n4; j4 += 4 * QT3) {                                                      \
-            float4 t4[4];                                                                                \
-            _Pragma("unroll") for (int g = 0; g < 4; ++g) {      /* four 16-byte loads in flight */       \
-                const int i0 = (j4 + g * QT3) * 4;                                                        \
-                if (i0 + 3 < a.N) {                                                                      \
-                    t4[g] = *reinterpret_cast<const float4*>(row + i0);                                  \
-                } else {                                                                                 \
-                    t4[g].x = (i0 + 0 < a.N) ? row[i0 + 0] : NAN;                                        \
-                    t4[g].y = (i0 + 1 < a.N) ? row[i0 + 1] : NAN;                                        \
-                    t4[g].z = (i0 + 2 < a.N) ? row[i0 + 2] : NAN;                                        \
-                    t4[g].w = NAN;                                                                       \
-                }                                                                                        \
-            }                                                                                            \
-            _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                              \
-                const int i0 = (j4 + g * QT3) * 4;                                                        \
-                const float vv[4] = {t4[g].x, t4[g].y, t4[g].z, t4[g].w};                                \
-                int x_ = masked ? i0 / a.P : 0, y_ = masked ? i0 % a.P : 0;                              \
-                _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                          \
-                    const float v = vv[u];                                                               \
-                    if (keep_at(x_, y_, v)) { BODY }                                                     \
-                    if (masked && ++y_ >= a.P) { y_ = 0; ++x_; }                                         \
-                }                                                                                        \
-            }                                                                                            \
-        }                                                                                                \
-    } else {                                                                                             \
-        for (int i0 = tid; i0 < a.N; i0 += 4 * QT3) {                                                     \
-            float vv[4];                                                                                 \
-            _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                              \
-                const int i = i0 + u * QT3;                                                               \
-                vv[u] = i < a.N ? row[(int64_t)i * a.s_elem] : NAN;                                      \
-            }                                                                                            \
-            _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                              \
-                const int i = i0 + u * QT3;                                                               \
-                const float v = vv[u];                                                                   \
-                if (keep_at(masked ? i / a.P : 0, masked ? i % a.P : 0, v)) { BODY }                     \
-            }                                                                                            \
-        }                                                                                                \
-    }
 
-    // ---- pass 0: top 12 bits, one histogram for all quantiles (its total is n); the row sum rides along
+// Shared state of one row's workgroup (declared once in the kernel: the body below is instantiated per mask mode).
+struct QRowShared {
+    unsigned* hist0;           // [QB0 + 1]
+    unsigned* hist;            // [QMAX][QB1]
+    unsigned* wtot;            // [16]
+    unsigned* prefix;          // [QMAX]
+    unsigned* k;               // [QMAX]
+    unsigned* mn;              // [QMAX]
+    unsigned* next;            // [QMAX]
+    unsigned* n;               // [1]
+    double* sum_w;             // [QT3 / 64]
+    float* lma; float* lmb;
+};
+
+// Visit every element of the row once: f(v, keep).  16-byte loads (four in flight) when the row is contiguous.  keep is
+// false for NaN (nanquantile ignores it) and, for a masked job, for elements outside the wanted mask class; the position
+// (x, y) = (i / P, i % P) of a masked row advances incrementally (one division per thread and pass, not per load).
+template <bool MASKED, typename F>
+__device__ __forceinline__ void qrow_foreach(const QuantArgs& a, const float* __restrict__ row, const float* lma, const float* lmb,
+                                             bool vec, F&& f) {
+    const int tid = threadIdx.x, P = MASKED ? a.P : 1;
+    const bool wantpos = a.want != 0;
+    if (vec) {
+        const int n4 = (a.N + 3) >> 2;
+        constexpr int STEP = 4 * QT3;                        // elements between two consecutive float4 of a thread
+        int x_ = 0, y_ = 0;
+        const int dq = MASKED ? STEP / P : 0, dr = MASKED ? STEP - dq * P : 0;
+        if (MASKED) { x_ = (tid * 4) / P; y_ = tid * 4 - x_ * P; }
+        for (int j4 = tid; j4 < n4; j4 += 4 * QT3) {
+            float4 t4[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {                    // four 16-byte loads in flight
+                const int i0 = (j4 + g * QT3) * 4;
+                if (i0 + 3 < a.N) {
+                    t4[g] = *reinterpret_cast<const float4*>(row + i0);
+                } else {
+                    t4[g].x = (i0 + 0 < a.N) ? row[i0 + 0] : NAN;
+                    t4[g].y = (i0 + 1 < a.N) ? row[i0 + 1] : NAN;
+                    t4[g].z = (i0 + 2 < a.N) ? row[i0 + 2] : NAN;
+                    t4[g].w = NAN;
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float vv[4] = {t4[g].x, t4[g].y, t4[g].z, t4[g].w};
+                int xx = x_, yy = y_;
+                float fa = 0.f;
+                if (MASKED) fa = xx < P ? lma[xx] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float v = vv[u];
+                    bool keep = v == v;
+                    if (MASKED) {
+                        keep = keep && (((fa * lmb[yy]) != 0.f) == wantpos);
+                        if (++yy >= P) { yy = 0; ++xx; fa = xx < P ? lma[xx] : 0.f; }
+                    }
+                    f(v, keep);
+                }
+                if (MASKED) {                                // the thread's next float4 is STEP elements further
+                    y_ += dr; x_ += dq;
+                    if (y_ >= P) { y_ -= P; ++x_; }
+                }
+            }
+        }
+    } else {
+        for (int i0 = tid; i0 < a.N; i0 += 4 * QT3) {
+            float vv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * QT3;
+                vv[u] = i < a.N ? row[(int64_t)i * a.s_elem] : NAN;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * QT3;
+                const float v = vv[u];
+                bool keep = v == v;
+                if (MASKED && keep) { const int x = i / P; keep = ((lma[x] * lmb[i - x * P]) != 0.f) == wantpos; }
+                f(v, keep);
+            }
+        }
+    }
+}
+
+// The three levels of one row.  What keeps the instruction count per element down (the kernel is VALU-bound on the one CU
+// a row has -- 7.6 us per 1000 instructions per thread):
+//   * the mask arithmetic exists only in the MASKED instantiation (the 65536-element queue-logit rows carry none);
+//   * quantiles whose prefix so far is the same share ONE histogram (on the narrow-band rows of a young encoder all three
+//     quartiles sit in one 12-bit bin: one LDS add per element and level instead of three); a duplicate's prefix is
+//     replaced by a value no key has, its selection reads the histogram of the first quantile with that prefix;
+//   * the prefixes live in scalar registers and one test ("does this element match any of them") guards the rest;
+//   * the smallest key above each prefix (the interpolation partner) is tracked with compare + select + min, no branch.
+template <bool MASKED, int NQT>
+__device__ __forceinline__ void qrow_body(const QuantArgs& a, int r, const QRowShared& S) {
+    const int tid = threadIdx.x, NQ = a.NQ;
+    const float* row = a.x + (int64_t)r * a.s_row;
+    const bool vec = a.s_elem == 1 && ((reinterpret_cast<uintptr_t>(row) & 15u) == 0);
+    // ---- level 0: top 12 bits, one histogram for all quantiles (its total is n); the row sum rides along
     float lsum = 0.f;
-    CP2_Q_FOREACH(atomicAdd(&hist0[f2key(v) >> 20], 1u); lsum += v;)
-    __shared__ double sum_w[QT3 / 64];
+    qrow_foreach<MASKED>(a, row, S.lma, S.lmb, vec, [&](float v, bool keep) {
+        if (keep) { atomicAdd(&S.hist0[f2key(v) >> 20], 1u); lsum += v; }
+    });
     if (a.mean_out) {
         double ds = (double)lsum;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) ds += __shfl_xor(ds, off, 64);
-        if ((tid & 63) == 0) sum_w[tid >> 6] = ds;
+        if ((tid & 63) == 0) S.sum_w[tid >> 6] = ds;
     }
     __syncthreads();
     {
-        const unsigned h0 = hist0[4 * tid], h1 = hist0[4 * tid + 1], h2 = hist0[4 * tid + 2], h3 = hist0[4 * tid + 3];
+        const unsigned h0 = S.hist0[4 * tid], h1 = S.hist0[4 * tid + 1], h2 = S.hist0[4 * tid + 2], h3 = S.hist0[4 * tid + 3];
         const unsigned tot = h0 + h1 + h2 + h3;
-        const unsigned incl = block_scan_incl<QT3>(tot, wtot), excl = incl - tot;
-        if (tid == QT3 - 1) sh_n = incl;
+        const unsigned incl = block_scan_incl<QT3>(tot, S.wtot), excl = incl - tot;
+        if (tid == QT3 - 1) *S.n = incl;
         __syncthreads();
-        const unsigned n = sh_n;
+        const unsigned n = *S.n;
         if (a.mean_out && tid == 0) {
             double t = 0;
-            for (int i = 0; i < QT3 / 64; ++i) t += sum_w[i];
+            for (int i = 0; i < QT3 / 64; ++i) t += S.sum_w[i];
             a.mean_out[r] = (n == (unsigned)a.N) ? (float)(t / (double)a.N) : NAN;   // a NaN element makes torch's mean NaN
         }
         if (n == 0) {
@@ -503,75 +533,389 @@ __global__ __launch_bounds__(QT3) void quantiles_row_kernel(QuantJobs jobs) {
             if (lo >= excl && lo < incl) {
                 unsigned kk = lo - excl, b = 4 * tid;
                 if (kk >= h0) { kk -= h0; ++b; if (kk >= h1) { kk -= h1; ++b; if (kk >= h2) { kk -= h2; ++b; } } }
-                sh_prefix[j] = b;
-                sh_k[j] = kk;
+                S.prefix[j] = b;
+                S.k[j] = kk;
             }
         }
     }
-    // ---- passes 1 and 2: ten more bits each, one histogram per quantile
+    // ---- levels 1 and 2: ten more bits each, one histogram per DISTINCT prefix
+    constexpr unsigned NEVER = 0xFFFFFFFFu;                  // no key has this 12- / 22-bit prefix
+    int slot[NQT];
     for (int pass = 1; pass <= 2; ++pass) {
-        for (int i = tid; i < QMAX * QB1; i += QT3) (&hist[0][0])[i] = 0;
-        if (tid < QMAX) { sh_min[tid] = 0xFFFFFFFFu; sh_next[tid] = 0xFFFFFFFFu; }
+        for (int i = tid; i < QMAX * QB1; i += QT3) S.hist[i] = 0;
+        if (tid < QMAX) { S.mn[tid] = NEVER; S.next[tid] = NEVER; }
         __syncthreads();
-        unsigned pre[QMAX], mn[QMAX];
-#pragma unroll
-        for (int j = 0; j < QMAX; ++j) { pre[j] = j < NQ ? sh_prefix[j] : 0xFFFFFFFFu; mn[j] = 0xFFFFFFFFu; }
+        unsigned pre[NQT], eff[NQT], hi[NQT], mn[NQT];
         const int sh = pass == 1 ? 20 : 10;
-        CP2_Q_FOREACH(
+#pragma unroll
+        for (int j = 0; j < NQT; ++j) {
+            pre[j] = j < NQ ? (unsigned)__builtin_amdgcn_readfirstlane((int)S.prefix[j]) : NEVER;
+            slot[j] = j;
+#pragma unroll
+            for (int i = j - 1; i >= 0; --i)
+                if (pre[i] == pre[j]) slot[j] = i;
+            eff[j] = slot[j] == j ? pre[j] : NEVER;
+            hi[j] = (pass == 2 && j < NQ) ? ((pre[j] << 10) | (unsigned)(QB1 - 1)) : NEVER;   // keys above it have a larger prefix
+            mn[j] = NEVER;
+        }
+        qrow_foreach<MASKED>(a, row, S.lma, S.lmb, vec, [&](float v, bool keep) {
             const unsigned k = f2key(v);
             const unsigned top = k >> sh;
-            const unsigned bin = (k >> (sh - 10)) & (QB1 - 1);
-            _Pragma("unroll") for (int j = 0; j < QMAX; ++j) {
-                if (top == pre[j]) atomicAdd(&hist[j][bin], 1u);
-                else if (pass == 2 && j < NQ && top > pre[j]) mn[j] = min(mn[j], k);
-            })
+            bool any = false;
+#pragma unroll
+            for (int j = 0; j < NQT; ++j) any = any || top == eff[j];
+            if (keep && any) {
+                const unsigned bin = (k >> (sh - 10)) & (QB1 - 1);
+#pragma unroll
+                for (int j = 0; j < NQT; ++j)
+                    if (top == eff[j]) atomicAdd(&S.hist[j * QB1 + bin], 1u);
+            }
+            if (pass == 2) {
+#pragma unroll
+                for (int j = 0; j < NQT; ++j) mn[j] = min(mn[j], (keep && k > hi[j]) ? k : NEVER);
+            }
+        });
         if (pass == 2) {
 #pragma unroll
-            for (int j = 0; j < QMAX; ++j) {
+            for (int j = 0; j < NQT; ++j) {
                 unsigned m = mn[j];
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, off, 64));
-                if ((tid & 63) == 0 && m != 0xFFFFFFFFu) atomicMin(&sh_min[j], m);
+                if ((tid & 63) == 0 && m != NEVER) atomicMin(&S.mn[j], m);
             }
         }
         __syncthreads();
-        for (int j = 0; j < NQ; ++j) {
-            const unsigned hv = hist[j][tid];
-            const unsigned incl = block_scan_incl<QT3>(hv, wtot), excl = incl - hv;
-            const unsigned kk0 = sh_k[j];
-            __syncthreads();                               // everyone has read sh_k[j] before it is rewritten
+#pragma unroll
+        for (int j = 0; j < NQT; ++j) {
+            if (j >= NQ) break;
+            const unsigned hv = S.hist[slot[j] * QB1 + tid];
+            const unsigned incl = block_scan_incl<QT3>(hv, S.wtot), excl = incl - hv;
+            const unsigned kk0 = S.k[j];
+            __syncthreads();                               // everyone has read k[j] before it is rewritten
             if (kk0 >= excl && kk0 < incl) {
-                sh_prefix[j] = (pre[j] << 10) | (unsigned)tid;
-                sh_k[j] = kk0 - excl;
+                S.prefix[j] = (pre[j] << 10) | (unsigned)tid;
+                S.k[j] = kk0 - excl;
             }
             __syncthreads();
             if (pass == 2) {
                 // the next non-empty bin above the selected one (the partner when the selected key is not repeated)
-                const unsigned sel = sh_prefix[j] & (QB1 - 1);
-                if (hv != 0 && (unsigned)tid > sel) atomicMin(&sh_next[j], (unsigned)tid);
+                const unsigned sel = S.prefix[j] & (QB1 - 1);
+                if (hv != 0 && (unsigned)tid > sel) atomicMin(&S.next[j], (unsigned)tid);
             }
         }
         __syncthreads();
     }
     if (tid < NQ) {
         const int j = tid;
-        const unsigned n = sh_n;
+        const unsigned n = *S.n;
         const float rank = a.q[j] * (float)(n - 1);
         const float lo_f = floorf(rank), w = rank - lo_f;
-        const unsigned key_lo = sh_prefix[j];
+        const unsigned key_lo = S.prefix[j];
         const float v_lo = key2f(key_lo);
         float v_hi = v_lo;
         if (w != 0.f) {
-            const unsigned mult = hist[j][key_lo & (QB1 - 1)];
-            if (sh_k[j] + 1 >= mult) {                     // the element of rank lo + 1 is a larger key
-                if (sh_next[j] != 0xFFFFFFFFu) v_hi = key2f((key_lo & ~(unsigned)(QB1 - 1)) | sh_next[j]);
-                else if (sh_min[j] != 0xFFFFFFFFu) v_hi = key2f(sh_min[j]);
+            int sj = j;                                      // the histogram this quantile shared on the last level
+            for (int i = j - 1; i >= 0; --i)
+                if ((S.prefix[i] >> 10) == (key_lo >> 10)) sj = i;
+            const unsigned mult = S.hist[sj * QB1 + (key_lo & (QB1 - 1))];
+            if (S.k[j] + 1 >= mult) {                      // the element of rank lo + 1 is a larger key
+                if (S.next[j] != NEVER) v_hi = key2f((key_lo & ~(unsigned)(QB1 - 1)) | S.next[j]);
+                else if (S.mn[j] != NEVER) v_hi = key2f(S.mn[j]);
             }
         }
         const float d = v_hi - v_lo;                         // at::lerp: w < 0.5 ? a + w*(b-a) : b - (b-a)*(1-w)
         a.out[(int64_t)j * a.R + r] = (w < 0.5f) ? v_lo + w * d : v_hi - d * (1.f - w);
     }
-#undef CP2_Q_FOREACH
+}
+
+// Histogram adds of FOUR consecutive elements per lane (one 16-byte load) for a converged 64-lane wavefront.  The logits of
+// a young encoder lie in a band a few float bins wide, where 256 adds to one LDS address serialise: if every element of
+// every lane is wanted and has the same bin, lane 0 adds 256 at once (one readfirstlane + compares + one ballot per
+// four elements); otherwise the lanes add for themselves.
+__device__ __forceinline__ void hist_add4_wave(unsigned* h, const unsigned (&bin)[4], const bool (&pred)[4]) {
+    const unsigned b0 = (unsigned)__builtin_amdgcn_readfirstlane((int)bin[0]);
+    const bool uni = pred[0] && pred[1] && pred[2] && pred[3] && bin[0] == b0 && bin[1] == b0 && bin[2] == b0 && bin[3] == b0;
+    if (__ballot(!uni) == 0ull) {
+        if ((threadIdx.x & 63) == 0) atomicAdd(&h[b0], 256u);
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (pred[u]) atomicAdd(&h[bin[u]], 1u);
+    }
+}
+
+// Inclusive scans of NV values per thread at once over the QT3 threads (one pair of barriers for all of them).
+template <int NV>
+__device__ __forceinline__ void block_scan_incl_n(unsigned (&v)[NV], unsigned* wtot /* [16 * NV] */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned t = (unsigned)__shfl_up((int)v[q], off, 64);
+            if (lane >= off) v[q] += t;
+        }
+    }
+    __syncthreads();                                       // wtot may still be read by the previous scan
+    if (lane == 63) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) wtot[q * 16 + w] = v[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        unsigned base = 0;
+        for (int j = 0; j < w; ++j) base += wtot[q * 16 + j];
+        v[q] += base;
+    }
+}
+
+// The same three levels with the row held in registers: F4 16-byte loads per thread, all in flight at once, converted to
+// keys on arrival (an element that is not kept -- NaN, outside the mask class, beyond N -- becomes key 0xFFFFFFFF, the
+// image of no kept float: it matches no prefix and is the neutral element of the "smallest key above" minimum, so levels
+// 1 and 2 need neither the mask nor the NaN test nor memory).  N <= F4 * 4 * QT3, contiguous 16-byte aligned rows.
+template <bool MASKED, int NQT, int F4>
+__device__ __forceinline__ void qrow_body_cached(const QuantArgs& a, int r, const QRowShared& S) {
+    constexpr unsigned NEVER = 0xFFFFFFFFu;
+    const int tid = threadIdx.x, NQ = a.NQ, P = MASKED ? a.P : 1;
+    const float* row = a.x + (int64_t)r * a.s_row;
+    const bool wantpos = a.want != 0;
+    unsigned key[F4 * 4];
+    float lsum = 0.f;
+    {
+        constexpr int STEP = 4 * QT3;
+        int x_ = 0, y_ = 0;
+        const int dq = MASKED ? STEP / P : 0, dr = MASKED ? STEP - dq * P : 0;
+        if (MASKED) { x_ = (tid * 4) / P; y_ = tid * 4 - x_ * P; }
+        // ---- level 0: top 12 bits, one histogram for all quantiles (its total is n); the row sum rides along.
+        // Loads in batches of at most eight (the keys of the whole row stay live: 64 registers at F4 = 16).
+        constexpr int BATCH = F4 > 8 ? (F4 + 1) / 2 : F4;
+#pragma unroll
+        for (int g0 = 0; g0 < F4; g0 += BATCH) {
+            float4 t4[BATCH];
+#pragma unroll
+            for (int gb = 0; gb < BATCH; ++gb) {
+                const int g = g0 + gb;
+                if (g >= F4) break;
+                const int i0 = (tid + g * QT3) * 4;
+                if (i0 + 3 < a.N) {
+                    t4[gb] = *reinterpret_cast<const float4*>(row + i0);
+                } else {
+                    t4[gb].x = (i0 + 0 < a.N) ? row[i0 + 0] : NAN;
+                    t4[gb].y = (i0 + 1 < a.N) ? row[i0 + 1] : NAN;
+                    t4[gb].z = (i0 + 2 < a.N) ? row[i0 + 2] : NAN;
+                    t4[gb].w = NAN;
+                }
+            }
+#pragma unroll
+            for (int gb = 0; gb < BATCH; ++gb) {
+                const int g = g0 + gb;
+                if (g >= F4) break;
+                const float vv[4] = {t4[gb].x, t4[gb].y, t4[gb].z, t4[gb].w};
+                int xx = x_, yy = y_;
+                float fa = 0.f;
+                if (MASKED) fa = xx < P ? S.lma[xx] : 0.f;
+                unsigned bin[4];
+                bool keep[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float v = vv[u];
+                    keep[u] = v == v;
+                    if (MASKED) {
+                        keep[u] = keep[u] && (((fa * S.lmb[yy]) != 0.f) == wantpos);
+                        if (++yy >= P) { yy = 0; ++xx; fa = xx < P ? S.lma[xx] : 0.f; }
+                    }
+                    const unsigned k = keep[u] ? f2key(v) : NEVER;
+                    key[g * 4 + u] = k;
+                    bin[u] = k >> 20;
+                    lsum += keep[u] ? v : 0.f;
+                }
+                hist_add4_wave(S.hist0, bin, keep);
+                if (MASKED) {
+                    y_ += dr; x_ += dq;
+                    if (y_ >= P) { y_ -= P; ++x_; }
+                }
+            }
+        }
+    }
+    if (a.mean_out) {
+        double ds = (double)lsum;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ds += __shfl_xor(ds, off, 64);
+        if ((tid & 63) == 0) S.sum_w[tid >> 6] = ds;
+    }
+    __syncthreads();
+    {
+        const unsigned h0 = S.hist0[4 * tid], h1 = S.hist0[4 * tid + 1], h2 = S.hist0[4 * tid + 2], h3 = S.hist0[4 * tid + 3];
+        const unsigned tot = h0 + h1 + h2 + h3;
+        const unsigned incl = block_scan_incl<QT3>(tot, S.wtot), excl = incl - tot;
+        if (tid == QT3 - 1) *S.n = incl;
+        __syncthreads();
+        const unsigned n = *S.n;
+        if (a.mean_out && tid == 0) {
+            double t = 0;
+            for (int i = 0; i < QT3 / 64; ++i) t += S.sum_w[i];
+            a.mean_out[r] = (n == (unsigned)a.N) ? (float)(t / (double)a.N) : NAN;   // a NaN element makes torch's mean NaN
+        }
+        if (n == 0) {
+            if (tid < NQ) a.out[(int64_t)tid * a.R + r] = NAN;
+            return;
+        }
+        for (int j = 0; j < NQ; ++j) {
+            const unsigned lo = (unsigned)floorf(a.q[j] * (float)(n - 1));
+            if (lo >= excl && lo < incl) {
+                unsigned kk = lo - excl, b = 4 * tid;
+                if (kk >= h0) { kk -= h0; ++b; if (kk >= h1) { kk -= h1; ++b; if (kk >= h2) { kk -= h2; ++b; } } }
+                S.prefix[j] = b;
+                S.k[j] = kk;
+            }
+        }
+    }
+    // ---- levels 1 and 2 on the keys in registers: one histogram per DISTINCT prefix
+    int slot[NQT];
+    for (int pass = 1; pass <= 2; ++pass) {
+        for (int i = tid; i < NQT * QB1; i += QT3) S.hist[i] = 0;
+        if (tid < QMAX) { S.mn[tid] = NEVER; S.next[tid] = NEVER; }
+        __syncthreads();
+        unsigned pre[NQT], eff[NQT], hi[NQT], mn[NQT];
+        const int sh = pass == 1 ? 20 : 10;
+#pragma unroll
+        for (int j = 0; j < NQT; ++j) {
+            pre[j] = j < NQ ? (unsigned)__builtin_amdgcn_readfirstlane((int)S.prefix[j]) : NEVER;
+            slot[j] = j;
+#pragma unroll
+            for (int i = j - 1; i >= 0; --i)
+                if (pre[i] == pre[j]) slot[j] = i;
+            eff[j] = slot[j] == j ? pre[j] : NEVER;
+            hi[j] = (pass == 2 && j < NQ) ? ((pre[j] << 10) | (unsigned)(QB1 - 1)) : NEVER;
+            mn[j] = NEVER;
+        }
+#pragma unroll
+        for (int g = 0; g < F4; ++g) {
+            unsigned top[4];
+            bool any = false;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                top[u] = key[g * 4 + u] >> sh;
+#pragma unroll
+                for (int j = 0; j < NQT; ++j) any = any || top[u] == eff[j];
+            }
+            if (__ballot(any) != 0ull) {                     // wave-uniform: most wavefronts of a spread-out row skip this
+                unsigned bin[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bin[u] = (key[g * 4 + u] >> (sh - 10)) & (QB1 - 1);
+#pragma unroll
+                for (int j = 0; j < NQT; ++j) {
+                    if (eff[j] == NEVER) continue;            // a duplicate prefix (scalar test)
+                    const bool m[4] = {top[0] == eff[j], top[1] == eff[j], top[2] == eff[j], top[3] == eff[j]};
+                    hist_add4_wave(S.hist + j * QB1, bin, m);
+                }
+            }
+            if (pass == 2) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned k = key[g * 4 + u];
+#pragma unroll
+                    for (int j = 0; j < NQT; ++j) mn[j] = min(mn[j], k > hi[j] ? k : NEVER);
+                }
+            }
+        }
+        if (pass == 2) {
+#pragma unroll
+            for (int j = 0; j < NQT; ++j) {
+                unsigned m = mn[j];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, off, 64));
+                if ((tid & 63) == 0 && m != NEVER) atomicMin(&S.mn[j], m);
+            }
+        }
+        __syncthreads();
+        unsigned hv[NQT], sc[NQT];
+#pragma unroll
+        for (int j = 0; j < NQT; ++j) { hv[j] = S.hist[slot[j] * QB1 + tid]; sc[j] = hv[j]; }
+        block_scan_incl_n<NQT>(sc, S.wtot);
+        unsigned kk0[NQT];
+#pragma unroll
+        for (int j = 0; j < NQT; ++j) kk0[j] = j < NQ ? S.k[j] : 0u;
+        __syncthreads();                                   // everyone has read k[] before it is rewritten
+#pragma unroll
+        for (int j = 0; j < NQT; ++j) {
+            const unsigned excl = sc[j] - hv[j];
+            if (j < NQ && kk0[j] >= excl && kk0[j] < sc[j]) {
+                S.prefix[j] = (pre[j] << 10) | (unsigned)tid;
+                S.k[j] = kk0[j] - excl;
+            }
+        }
+        __syncthreads();
+        if (pass == 2) {
+#pragma unroll
+            for (int j = 0; j < NQT; ++j) {
+                if (j >= NQ) break;
+                // the next non-empty bin above the selected one (the partner when the selected key is not repeated)
+                const unsigned sel = S.prefix[j] & (QB1 - 1);
+                if (hv[j] != 0 && (unsigned)tid > sel) atomicMin(&S.next[j], (unsigned)tid);
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < NQ) {
+        const int j = tid;
+        const unsigned n = *S.n;
+        const float rank = a.q[j] * (float)(n - 1);
+        const float lo_f = floorf(rank), w = rank - lo_f;
+        const unsigned key_lo = S.prefix[j];
+        const float v_lo = key2f(key_lo);
+        float v_hi = v_lo;
+        if (w != 0.f) {
+            int sj = j;                                      // the histogram this quantile shared on the last level
+            for (int i = j - 1; i >= 0; --i)
+                if ((S.prefix[i] >> 10) == (key_lo >> 10)) sj = i;
+            const unsigned mult = S.hist[sj * QB1 + (key_lo & (QB1 - 1))];
+            if (S.k[j] + 1 >= mult) {                      // the element of rank lo + 1 is a larger key
+                if (S.next[j] != NEVER) v_hi = key2f((key_lo & ~(unsigned)(QB1 - 1)) | S.next[j]);
+                else if (S.mn[j] != NEVER) v_hi = key2f(S.mn[j]);
+            }
+        }
+        const float d = v_hi - v_lo;                         // at::lerp: w < 0.5 ? a + w*(b-a) : b - (b-a)*(1-w)
+        a.out[(int64_t)j * a.R + r] = (w < 0.5f) ? v_lo + w * d : v_hi - d * (1.f - w);
+    }
+}
+
+__global__ __launch_bounds__(QT3) void quantiles_row_kernel(QuantJobs jobs) {
+    int jsel = 0;
+#pragma unroll
+    for (int j = 1; j < QJOBS; ++j) jsel += ((int)blockIdx.x >= jobs.first_row[j]) ? 1 : 0;
+    const QuantArgs& a = jobs.job[jsel];
+    extern __shared__ __attribute__((aligned(16))) unsigned char q_smem[];
+    __shared__ unsigned hist0[QB0];
+    __shared__ unsigned hist[QMAX * QB1];
+    __shared__ unsigned wtot[16 * QMAX];
+    __shared__ unsigned sh_prefix[QMAX], sh_k[QMAX], sh_min[QMAX], sh_next[QMAX], sh_n;
+    __shared__ double sum_w[QT3 / 64];
+    const bool masked = a.want >= 0;
+    QRowShared S;
+    S.hist0 = hist0; S.hist = hist; S.wtot = wtot; S.prefix = sh_prefix; S.k = sh_k; S.mn = sh_min; S.next = sh_next; S.n = &sh_n;
+    S.sum_w = sum_w;
+    S.lma = reinterpret_cast<float*>(q_smem);
+    S.lmb = S.lma + (masked ? a.P : 0);
+    const int r = (int)blockIdx.x - jobs.first_row[jsel], tid = threadIdx.x;
+    if (masked) {
+        for (int i = tid; i < a.P; i += QT3) { S.lma[i] = a.mask_a[(int64_t)r * a.P + i]; S.lmb[i] = a.mask_b[(int64_t)r * a.P + i]; }
+    }
+    for (int i = tid; i < QB0; i += QT3) hist0[i] = 0;
+    __syncthreads();
+    // NQ <= 3 (the step's quartiles) gets loops of three; a fourth quantile the general body.  Rows of at most 65536
+    // contiguous elements are held in registers through the three levels (the step: 38416 and 65536 elements).
+    const bool vec = a.s_elem == 1 && (((reinterpret_cast<uintptr_t>(a.x) | (uintptr_t)((int64_t)a.s_row * 4)) & 15u) == 0);
+    if (a.NQ <= 3 && vec && a.N <= 10 * 4 * QT3) {
+        if (masked) qrow_body_cached<true, 3, 10>(a, r, S); else qrow_body_cached<false, 3, 10>(a, r, S);
+    } else if (a.NQ <= 3 && vec && a.N <= 16 * 4 * QT3) {
+        if (masked) qrow_body_cached<true, 3, 16>(a, r, S); else qrow_body_cached<false, 3, 16>(a, r, S);
+    } else if (a.NQ <= 3) {
+        if (masked) qrow_body<true, 3>(a, r, S); else qrow_body<false, 3>(a, r, S);
+    } else {
+        if (masked) qrow_body<true, QMAX>(a, r, S); else qrow_body<false, QMAX>(a, r, S);
+    }
 }
 
 // ---- rows of at most QROW_MAX elements, a few hundred chunks in total (the training step: 576): ONE launch, one
