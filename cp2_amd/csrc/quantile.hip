@@ -7,7 +7,8 @@
 // torch.quantile(..., interpolation='linear'):  rank = q*(n-1) in fp32, lerp(v_lo, v_hi, frac).
 //
 // Two forms.  Rows of at most CP2_QUANTILES_ROW_MAX elements (the training step: 32 x 65536 queue logits + 2 x 32 x 196^2
-// dense pairs): quantiles_row_kernel, ONE launch, one workgroup per row through the three levels (66 us per step).
+// dense pairs): quantiles_row_kernel, ONE launch, one workgroup per row through the three levels (42 us per step; 66 before
+// the row was kept in registers).
 // Longer rows (BASELINE config 4: 16 rows of 16.7 M dense logits) are cut into 8192-element chunks and every level is
 // a chunk-parallel histogram pass with a tiny per-row select between the passes:
 //   K1  quantile_hist_kernel<0>   chunk: LDS histogram of the top 12 bits         -> global hist0 (atomic adds)
