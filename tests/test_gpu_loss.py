@@ -357,13 +357,18 @@ def _masked_quantiles_cases():
     # candidate lists overflow and the select re-reads the row), +-inf, and a workspace re-used by consecutive calls
     # (rows above 131072 elements take the chunked three-launch path, the others the one-launch row kernel)
     for R, N, kind in ((2, 3_000_000, "normal"), (3, 270_001, "const"), (3, 70_001, "const"), (2, 200_003, "band"),
-                       (2, 100_000, "band"), (2, 150_000, "inf"), (2, 50_000, "inf")):
+                       (2, 100_000, "band"), (2, 150_000, "inf"), (2, 50_000, "inf"),
+                       # rows the row kernel holds in registers (<= 65536 elements): one- and two-bin bands (every lane of a
+                       # wavefront adds to the same histogram bin), a band straddling 1.0, constants, a ragged tail
+                       (2, 60_000, "band"), (2, 40_000, "band"), (2, 65_536, "straddle"), (3, 30_001, "const"), (2, 40_961, "normal")):
         x = torch.randn(R, N, generator=gen) * 0.09
         if kind == "const":
             x[:] = -0.25
             x[2, 5] = 1.0
         elif kind == "band":
             x = 0.5 + torch.rand(R, N, generator=gen) * 1e-4
+        elif kind == "straddle":
+            x = 1.0 + torch.randn(R, N, generator=gen) * 1e-6
         elif kind == "inf":
             x[0, ::7] = float("inf")
             x[1, ::5] = float("-inf")
@@ -373,8 +378,15 @@ def _masked_quantiles_cases():
         for _ in range(2):
             got = ops.masked_quantiles(xd, N, 1, R, N, q=qs.to(DEV))
             assert np.array_equal(got.cpu().numpy(), want.numpy(), equal_nan=True), (R, N, kind)
+    # padded rows (row stride > N, 16-byte aligned): the register-resident path with a ragged last 16-byte load, 10 and 16 loads
+    for N, stride in ((40_961, 40_964), (65_533, 65_536), (5, 8)):
+        xp = torch.randn(3, stride, generator=gen)
+        xp[1, 3] = float("nan")
+        qs = torch.tensor([0.25, 0.5, 0.75])
+        got = ops.masked_quantiles(xp.to(DEV), stride, 1, 3, N, q=qs.to(DEV))
+        assert np.array_equal(got.cpu().numpy(), torch.nanquantile(xp[:, :N], qs, dim=1).numpy(), equal_nan=True), (N, stride)
     # masked form against the oracle's dense statistics
-    for B, P in ((2, 420), (2, 390), (2, 260), (2, 130)):       # P % 4 == 0 and != 0; chunked (P*P > 131072) and row kernel
+    for B, P in ((2, 420), (2, 390), (2, 260), (2, 240), (2, 196), (2, 130)):   # P % 4 == 0 and != 0; chunked (P*P > 131072), row kernel re-reading (260), registers (240: 16 loads, 196 / 130: 10)
         logits = torch.randn(B, P, P, generator=gen) * 0.1
         ma = (torch.rand(B, P, generator=gen) > 0.4).float()
         mb = (torch.rand(B, P, generator=gen) > 0.5).float()
