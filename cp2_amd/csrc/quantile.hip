@@ -788,7 +788,10 @@ __device__ __forceinline__ void qrow_body_cached(const QuantArgs& a, int r, cons
             for (int i = j - 1; i >= 0; --i)
                 if (pre[i] == pre[j]) slot[j] = i;
             eff[j] = slot[j] == j ? pre[j] : NEVER;
-            hi[j] = (pass == 2 && j < NQ) ? ((pre[j] << 10) | (unsigned)(QB1 - 1)) : NEVER;
+            // smallest key above the prefix: min over (k - hi1) mod 2^32 with hi1 = first key above the prefix's range.  Keys
+            // above give small values, the not-kept image 0xFFFFFFFF the largest of those, keys at or below wrap to still
+            // larger ones -- so the minimum is the wanted key whenever one exists (two instructions per element, no compare)
+            hi[j] = (pass == 2 && j < NQ) ? ((pre[j] << 10) | (unsigned)(QB1 - 1)) + 1u : 0u;
             mn[j] = NEVER;
         }
 #pragma unroll
@@ -817,7 +820,7 @@ __device__ __forceinline__ void qrow_body_cached(const QuantArgs& a, int r, cons
                 for (int u = 0; u < 4; ++u) {
                     const unsigned k = key[g * 4 + u];
 #pragma unroll
-                    for (int j = 0; j < NQT; ++j) mn[j] = min(mn[j], k > hi[j] ? k : NEVER);
+                    for (int j = 0; j < NQT; ++j) mn[j] = min(mn[j], k - hi[j]);
                 }
             }
         }
@@ -827,7 +830,8 @@ __device__ __forceinline__ void qrow_body_cached(const QuantArgs& a, int r, cons
                 unsigned m = mn[j];
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, off, 64));
-                if ((tid & 63) == 0 && m != NEVER) atomicMin(&S.mn[j], m);
+                const unsigned kmin = m + hi[j];                 // back to a key; below hi1 = wrapped = nothing above the prefix
+                if ((tid & 63) == 0 && j < NQ && kmin >= hi[j] && kmin != NEVER) atomicMin(&S.mn[j], kmin);
             }
         }
         __syncthreads();
