@@ -13,7 +13,8 @@ and one asynchronous all_reduce(SUM) over that range starts.  At the end of the 
 view of the flat gradient buffer (so `optim.FlatSGD` reads constant addresses).
 
 Every trainable parameter must receive a gradient in every synchronised backward pass, as with DDP's default
-find_unused_parameters=False (builder.MODEL freezes what the chosen path never uses).
+find_unused_parameters=False (builder.MODEL freezes what the chosen path never uses); which parameters are trainable is
+read once, at construction (freeze or unfreeze afterwards: build a new FlatDDP, as with DDP).
 """
 from __future__ import annotations
 
@@ -110,7 +111,7 @@ class GradReducer:
         return hook
 
     def _ready(self, i: int) -> None:
-        if not self.enabled or self.world == 1 and not cdist.FORCE_COLLECTIVES:
+        if not self.enabled or (self.world == 1 and not cdist.FORCE_COLLECTIVES):
             return
         if not self._armed:
             self._armed = True
