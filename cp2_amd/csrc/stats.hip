@@ -35,7 +35,21 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 __global__ __launch_bounds__(256) void step_scalars_kernel(StepScalarArgs a) {
     __shared__ double red[4];
     __shared__ double col[8];
+    // Both [B][C] matrices of the cross-image spread are staged in LDS when they fit (the training step: 32 x 128 floats each);
+    // their loads are issued FIRST, so the column sums and quartile means below run while they are in flight and the launch
+    // pays one memory round trip, not one per section (12.7 -> 8 us; a first version walked global memory per channel: 24 us).
+    constexpr int kTile = 4096;
+    __shared__ float tile[2][kTile];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, B = a.B;
+    const int BC = B * a.C;
+    const bool staged = BC <= kTile && (BC & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.q_pos) | reinterpret_cast<uintptr_t>(a.k_pos)) & 15u) == 0;
+    if (staged) {
+        for (int e = tid; e < BC / 4; e += 256) {
+            const float4 vq = reinterpret_cast<const float4*>(a.q_pos)[e], vk = reinterpret_cast<const float4*>(a.k_pos)[e];
+            reinterpret_cast<float4*>(tile[0])[e] = vq;
+            reinterpret_cast<float4*>(tile[1])[e] = vk;
+        }
+    }
     // ---- wave 0: the per-sample columns (B is a batch size: one short loop per lane)
     if (w == 0) {
         double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -77,38 +91,23 @@ __global__ __launch_bounds__(256) void step_scalars_kernel(StepScalarArgs a) {
             for (int k = 0; k < 3; ++k)
                 if (!a.quart[j]) a.out[11 + 3 * j + k] = 0.f;
     }
-    // ---- all waves: unbiased std over the batch per channel, mean over channels (two passes, double).  The [B][C] matrix
-    // is staged in LDS with coalesced 16-byte loads when it fits (the training step: 32 x 128 floats); a thread then owns a
-    // channel and walks the batch in LDS.  (A first version walked global memory: 2 x 2 x B dependent loads per thread, 24 us.)
-    constexpr int kTile = 8192;
-    __shared__ float tile[kTile];
-    const int BC = B * a.C;
-    const bool staged = BC <= kTile && (BC & 3) == 0;
-    for (int side = 0; side < 2; ++side) {
-        const float* v = side ? a.k_pos : a.q_pos;
-        __syncthreads();                               // the tile (and red[]) of the previous side are done with
-        const bool vec = staged && ((reinterpret_cast<uintptr_t>(v) & 15u) == 0);
-        if (vec) {
-            for (int e = tid; e < BC / 4; e += 256) reinterpret_cast<float4*>(tile)[e] = reinterpret_cast<const float4*>(v)[e];
-        } else if (staged) {
-            for (int e = tid; e < BC; e += 256) tile[e] = v[e];
-        }
-        __syncthreads();
-        const float* src = staged ? tile : v;
-        double acc = 0;
-        for (int c = tid; c < a.C; c += 256) {
-            double m = 0;
-            for (int n = 0; n < B; ++n) m += src[(int64_t)n * a.C + c];
-            m /= B;
-            double ss = 0;
-            for (int n = 0; n < B; ++n) { const double d = src[(int64_t)n * a.C + c] - m; ss += d * d; }
-            acc += sqrt(ss / (B - 1));                 // B = 1: 0/0 = NaN, as torch.std
-        }
-        acc = wave_sum_d(acc);
-        if (lane == 0) red[w] = acc;
-        __syncthreads();
-        if (tid == 0) a.out[9 + side] = (float)((red[0] + red[1] + red[2] + red[3]) / a.C);
+    // ---- unbiased std over the batch per channel, mean over channels (two passes, double): waves 0-1 take q_pos, waves 2-3
+    // k_pos; a thread owns a channel and walks the batch (in LDS when staged)
+    const int side = tid >> 7, t2 = tid & 127;
+    const float* src = staged ? tile[side] : (side ? a.k_pos : a.q_pos);
+    double acc = 0;
+    for (int c = t2; c < a.C; c += 128) {
+        double m = 0;
+        for (int n = 0; n < B; ++n) m += src[(int64_t)n * a.C + c];
+        m /= B;
+        double ss = 0;
+        for (int n = 0; n < B; ++n) { const double d = src[(int64_t)n * a.C + c] - m; ss += d * d; }
+        acc += sqrt(ss / (B - 1));                     // B = 1: 0/0 = NaN, as torch.std
     }
+    acc = wave_sum_d(acc);
+    if (lane == 0) red[w] = acc;
+    __syncthreads();
+    if (tid < 2) a.out[9 + tid] = (float)((red[2 * tid] + red[2 * tid + 1]) / a.C);
 }
 
 CP2_API int cp2_step_scalars(const float* ins_loss, const int32_t* cnt_gt, const float* extras, int NE, const float* sample_scal,
