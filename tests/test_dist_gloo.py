@@ -79,7 +79,7 @@ def _worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(120)
-@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_world_n_gloo_collectives(tmp_path, world):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     q0, q1 = torch.load(tmp_path / "q0.pt"), torch.load(tmp_path / "q1.pt")
