@@ -110,7 +110,7 @@ def _worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(180)
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_grad_reducer_equals_ddp(tmp_path, world):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     outs = [torch.load(tmp_path / f"r{r}.pt") for r in range(world)]
