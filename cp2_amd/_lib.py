@@ -43,6 +43,8 @@ SIGNATURES = {
                                c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, c_int, _P],
     "cp2_rowkey_infonce_finalize": [_P, _P, _P, _P, c_int, _P, c_int, c_float, c_float, c_int, c_int, c_int64,
                                     c_int64, c_int64, _P, _P, _P, _P, _P, _P, c_int, _P],
+    "cp2_densecl_match": [_P, _P, c_int, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P, c_float, c_float,
+                          c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "cp2_dense_num_splits": [c_int, c_int],
     "cp2_dense_infonce_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, _P, _P, _P, _P,
                               _P, _P, _P, _P, _P, _P, c_int, c_float, _P, c_int, c_int, c_int, _P],

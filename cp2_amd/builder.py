@@ -113,6 +113,50 @@ class DenseCLNeck(nn.Module):
                 "x_avgpool_local_proj": self.avgpool_local(l_proj).flatten(1)}
 
 
+STATS_CHUNK_BYTES = 128 << 20     # raw-logit buffer of the rows-vs-queue score statistics (rank 0, logging): see _queue_infonce_chunked
+
+
+def _queue_infonce_chunked(rows, ext, queue, temperature, layout, R, need):
+    """rows-vs-queue InfoNCE WITH the per-row score statistics for row counts whose raw logits do not fit a cache-sized
+    buffer (DenseCL local loss on rank 0: 6272 x 65536 fp32 = 1.64 GB, which the reference materialises and sorts,
+    builder.py:871-886).  The rows are walked in groups of whole samples: each group's loss / gradient launch writes its
+    raw logits into ONE re-used buffer of at most STATS_CHUNK_BYTES (it stays in the 256 MB Infinity Cache), the radix-select
+    launch behind it reads them back -- same kernels, same per-row results, bit for bit, as the one-shot form; the queue's
+    bf16 split is made once.  Returns (loss, drows, dE, neg_mean [R], neg_quartiles [3,R])."""
+    C, K = queue.shape
+    per = max(1, STATS_CHUNK_BYTES // (4 * K))
+    if rows.dim() == 3:
+        b, _, S2 = rows.shape
+        m = max(1, per // S2)
+        spans = [(n0, min(b, n0 + m), S2) for n0 in range(0, b, m)]
+    else:
+        spans = [(r0, min(R, r0 + per), 1) for r0 in range(0, R, per)]
+    dev = rows.device
+    lbuf = torch.empty(max((a1 - a0) * rp for a0, a1, rp in spans) * K, dtype=torch.float32, device=dev)
+    drows = torch.empty_like(rows) if need else None
+    neg_mean = torch.empty(R, dtype=torch.float32, device=dev)
+    row_form = K <= ops.QUANTILES_ROW_MAX
+    loss_rows, dE, quart = [], [], []
+    ksplit = None
+    precision = "bf16x3" if R >= 1024 else "f32"        # what "auto" picks for the whole call (a group alone may fall below)
+    for a0, a1, rp in spans:
+        r0, Rc = a0 * rp, (a1 - a0) * rp
+        res = ops.rowkey_infonce(rows[a0:a1], layout, Rc, queue, ext[r0:r0 + Rc], temperature,
+                                 grad_scale=(1.0 / R) if need else None, want_lneg=True, lneg_row_major=True,
+                                 precision=precision, ksplit=ksplit, ksplit_ready=ksplit is not None, lneg_out=lbuf,
+                                 drows_out=drows[a0:a1] if need else None)
+        ksplit = res.ksplit
+        loss_rows.append(res.loss_rows)
+        if need:
+            dE.append(res.dE)
+        mean_out = neg_mean[r0:r0 + Rc]
+        quart.append(ops.masked_quantiles_multi([dict(x=res.lneg, stride_row=K, stride_elem=1, R=Rc, N=K,
+                                                      mean_out=mean_out if row_form else None)])[0])
+        if not row_form:
+            mean_out.copy_(res.lneg.mean(1))
+    return torch.cat(loss_rows).mean(), drows, (torch.cat(dE) if need else None), neg_mean, torch.cat(quart, dim=1)
+
+
 class _QueueInfoNCEFn(torch.autograd.Function):
     """InfoNCE of row vectors against a queue (reference ContrastiveHead, builder.py:150-176, fed by
     :762-772 or :866-873): one fused kernel pass, gradients for rows and positives produced in forward."""
@@ -120,16 +164,23 @@ class _QueueInfoNCEFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rows, pos, queue, temperature, layout, R, stats):
         need = rows.requires_grad or pos.requires_grad
-        res = ops.rowkey_infonce(rows, layout, R, queue, pos.reshape(R, 1).contiguous(), temperature,
-                                 grad_scale=(1.0 / R) if need else None, want_lneg=stats is not None,
-                                 lneg_row_major=stats is not None)
+        K = queue.shape[1]
+        ext = pos.reshape(R, 1).contiguous()
+        if stats is not None and R * K * 4 > STATS_CHUNK_BYTES:
+            loss, drows, dE, stats["neg_mean"], stats["neg_quartiles"] = _queue_infonce_chunked(rows, ext, queue, temperature,
+                                                                                                 layout, R, need)
+        else:
+            res = ops.rowkey_infonce(rows, layout, R, queue, ext, temperature, grad_scale=(1.0 / R) if need else None,
+                                     want_lneg=stats is not None, lneg_row_major=stats is not None)
+            loss, drows, dE = res.loss, res.drows, res.dE
+            if stats is not None:   # reference builder.py:776-786 / :876-886: mean and quartiles of every row's negatives
+                row_form = K <= ops.QUANTILES_ROW_MAX
+                stats["neg_mean"] = torch.empty(R, dtype=torch.float32, device=rows.device) if row_form else res.lneg.mean(1)
+                stats["neg_quartiles"] = ops.masked_quantiles_multi([dict(x=res.lneg, stride_row=K, stride_elem=1, R=R, N=K,
+                                                                          mean_out=stats["neg_mean"] if row_form else None)])[0]
         if need:
-            ctx.save_for_backward(res.drows, res.dE.reshape(pos.shape))
-        if stats is not None:       # reference builder.py:776-786 / :876-886: mean and quartiles of every row's negatives
-            K = queue.shape[1]
-            stats["neg_mean"] = res.lneg.mean(1)
-            stats["neg_quartiles"] = ops.masked_quantiles(res.lneg, K, 1, R, K)
-        return res.loss
+            ctx.save_for_backward(drows, dE.reshape(pos.shape))
+        return loss
 
     @staticmethod
     def backward(ctx, g):
@@ -150,27 +201,51 @@ def queue_infonce(rows: torch.Tensor, pos: torch.Tensor, queue: torch.Tensor, te
     return _QueueInfoNCEFn.apply(rows, pos.float(), queue, float(temperature), layout, R, stats)
 
 
-def densecl_local_positives(q_embed, k_embed, q_local, k_local, ids_q, ids_k, lmbd_coordinate: float = 0.0, metrics=None):
+class _LocalPositivesFn(torch.autograd.Function):
+    """pos, best = cp2_densecl_match(...) with d pos / d q_local = kvec (reference builder.py:818-855; the arg-max and the
+    key side carry no gradient)."""
+
+    @staticmethod
+    def forward(ctx, q_local, q_embed, k_embed, k_local, ids_q, ids_k, lmbd, k_row, normalize_k, metrics):
+        res = ops.densecl_match(q_embed, k_embed, q_local, k_local, ids_q, ids_k, lmbd, k_row=k_row, normalize_k=normalize_k,
+                                want_kvec=q_local.requires_grad, want_metrics=metrics is not None)
+        if metrics is not None:
+            metrics["counts"] = res.counts
+        if q_local.requires_grad:
+            ctx.save_for_backward(res.kvec)
+        ctx.mark_non_differentiable(res.best)
+        return res.pos, res.best
+
+    @staticmethod
+    def backward(ctx, g_pos, _g_best):
+        (kvec,) = ctx.saved_tensors
+        return (kvec * g_pos.unsqueeze(1),) + (None,) * 9
+
+
+def _matching_rate(counts: torch.Tensor) -> torch.Tensor:
+    """builder.py:856-864: how often the best local match is the coordinate match, over the overlapping pixels (-1: none)."""
+    tot = counts.sum(0)
+    return torch.where(tot[0] > 0, tot[1].float() / tot[0].clamp(min=1).float(), torch.full((), -1.0, device=counts.device))
+
+
+def densecl_local_positives(q_embed, k_embed, q_local, k_local, ids_q, ids_k, lmbd_coordinate: float = 0.0, metrics=None,
+                            k_row=None, normalize_k: bool = False):
     """Positive score of every query pixel for the DenseCL local loss (reference builder.py:818-855):
     local similarity with the key pixel that maximises the BACKBONE similarity; where the two id maps overlap it is
-    mixed with the summed local similarity over id-matching key pixels.  Inputs are channel-normalised (b, C, S2);
-    ids are (b, S2).  Returns (pos (b, S2), arg-max index (b, S2)).  Plain batched GEMMs (hipBLASLt) + gather."""
-    best = torch.bmm(q_embed.transpose(1, 2), k_embed).argmax(dim=2)
-    local_sim = torch.bmm(q_local.transpose(1, 2), k_local)
-    pos = torch.gather(local_sim, 2, best.unsqueeze(2)).squeeze(2)
-    if lmbd_coordinate > 0 or metrics is not None:
-        corr = ids_q[:, :, None] == ids_k[:, None, :]
-        overlap = corr.any(-1)
-    if lmbd_coordinate > 0:
-        coord = (local_sim * corr).sum(-1)
-        pos = torch.where(overlap, pos * (1 - lmbd_coordinate) + coord * lmbd_coordinate, pos)
+    mixed with the summed local similarity over id-matching key pixels.  One cp2_densecl_match launch; no b x S2 x S2
+    map exists.  q_embed / k_embed: (b, Cb, S2) or (b, Cb, h, w), channel-normalised (normalize_k=False) or the raw
+    backbone features (normalize_k=True; bf16 channels-last maps are read in place); q_local / k_local: (b, C, S2) unit
+    vectors; ids: (b, S2).  k_row: sample n's key side is row k_row[n].  Returns (pos (b, S2), arg-max index (b, S2));
+    differentiable with respect to q_local."""
+    q_local, k_local = q_local.float().contiguous(), k_local.detach().float().contiguous()
+    b, _, S2 = q_local.shape
+    ids_q = ids_q.reshape(b, S2).contiguous() if ids_q is not None else None
+    ids_k = ids_k.reshape(b, S2).contiguous() if ids_k is not None else None
+    pos, best = _LocalPositivesFn.apply(q_local, q_embed.detach(), k_embed.detach(), k_local, ids_q, ids_k,
+                                        float(lmbd_coordinate), k_row, bool(normalize_k), metrics)
     if metrics is not None:
-        # builder.py:856-864: how often the best local match is the coordinate match (over overlapping pixels; -1: none)
-        hit = (corr.float().argmax(2) == local_sim.argmax(2)) & overlap
-        n_ov = overlap.sum()
-        metrics["matching_positives_rate"] = torch.where(n_ov > 0, hit.sum().float() / n_ov.clamp(min=1).float(),
-                                                          torch.full((), -1.0, device=pos.device))
-    return pos, best
+        metrics["matching_positives_rate"] = _matching_rate(metrics.pop("counts"))
+    return pos, best.long()
 
 
 class _CommTimer:
@@ -548,6 +623,25 @@ class MODEL(nn.Module):
             w = cdist.world_size()
             return ops.gather_rows(concat_all_gather(x), idx_unshuffle.view(w, -1)[cdist.rank()].contiguous())
 
+    @torch.no_grad()
+    def _key_rows(self, feats, ctx):
+        """Key-encoder outputs of the shuffled batch -> (tensors, k_row) with sample n's features at row k_row[n] of each
+        tensor (k_row None: they are in sample order).  One rank: nothing moves, k_row is the un-shuffle index itself;
+        all-to-all exchange: the rows travel back and stay in arrival order (keep_order); the reference's all-gather form
+        (builder.py:632-649) returns them ordered."""
+        if isinstance(ctx, cdist.ShufflePlan):
+            outs = []
+            with self._comm("c3_key_unshuffle"):
+                for f in feats:
+                    if not (f.is_contiguous() or (f.dim() == 4 and f.is_contiguous(memory_format=torch.channels_last))):
+                        f = f.contiguous()
+                    rows, restore = _rows_as_f32(f)
+                    outs.append(restore(cdist.exchange_rows(rows, ctx, backward=True, take=ops.gather_rows, keep_order=True)))
+            return outs, ctx.device_tables(outs[0].device)[3]
+        if cdist.multi():
+            return [self._batch_unshuffle_ddp(f, ctx) for f in feats], None
+        return list(feats), ctx
+
     # ------------------------------------------------------------------ dispatch
     def forward(self, **kwargs):
         self.wait_enqueue()                     # the previous step's queue update (when it ran on the side stream)
@@ -698,25 +792,32 @@ class MODEL(nn.Module):
         pix_b = ops.strided_gather(pixel_ids_b.contiguous(), bs).reshape(b, -1)
 
         def query_features(img):
-            embd = self._encode(self.encoder_q.backbone, img)[3].float()
-            out = self.encoder_q.neck(embd)
+            feat = self._encode(self.encoder_q.backbone, img)[3]         # bf16 channels-last under autocast, else fp32
+            out = self.encoder_q.neck(feat.float())
             local = out["x_local_pred"] if self.use_predictor else out["x_local_proj"]
             glob = out["x_global_pred"] if self.use_predictor else out["x_global_proj"]
             if self.use_avgpool_global:
                 glob = out["x_avgpool_local_pred"] if self.use_predictor else out["x_avgpool_local_proj"]
-            return F.normalize(embd.flatten(2), dim=1), F.normalize(local.flatten(2), dim=1), F.normalize(glob, dim=1)
+            # the backbone map goes to cp2_densecl_match as it is: only its arg-max is used (no gradient, reference
+            # builder.py:818-821), and a positive factor per query pixel cannot change an arg-max -- no normalised copy
+            return feat.detach(), F.normalize(local.flatten(2), dim=1), F.normalize(glob, dim=1)
 
         @torch.no_grad()
         def key_features(img):
+            """-> (backbone map, local, global, pooled local, k_row): the two maps stay in the key encoder's (shuffled) row
+            order and sample n is row k_row[n] (None: already in sample order); the two vectors are in sample order."""
             if self.ema_in_forward:
                 self._momentum_update_key_encoder()
-            img, idx_un = self._batch_shuffle_ddp(img, idx_shuffle)
-            embd = self._encode(self.encoder_k.backbone, img)[3].float()
-            out = self.encoder_k.neck(embd)
+            img, ctx = self._batch_shuffle_ddp(img, idx_shuffle)
+            feat = self._encode(self.encoder_k.backbone, img)[3]
+            out = self.encoder_k.neck(feat.float())
             glob = out["x_avgpool_local_proj"] if self.use_avgpool_global else out["x_global_proj"]
-            feats = (F.normalize(embd.flatten(2), dim=1), F.normalize(out["x_local_proj"].flatten(2), dim=1),
-                     F.normalize(glob, dim=1), F.normalize(out["x_avgpool_local_proj"], dim=1))
-            return tuple(self._batch_unshuffle_ddp(f, idx_un) for f in feats)
+            local = F.normalize(out["x_local_proj"].flatten(2), dim=1)
+            glob, pooled = F.normalize(glob, dim=1), F.normalize(out["x_avgpool_local_proj"], dim=1)
+            (feat, local, glob, pooled), k_row = self._key_rows((feat, local, glob, pooled), ctx)
+            if k_row is not None:
+                glob, pooled = glob.index_select(0, k_row), pooled.index_select(0, k_row)
+            return feat, local, glob, pooled, k_row
 
         # rank 0 logs the score statistics of the FIRST pass (reference builder.py:774-804, 875-904: log_metrics=True there only)
         extra = {} if (self.rank == 0 and self.log_quartiles) else None
@@ -735,9 +836,10 @@ class MODEL(nn.Module):
                               "step/cross_image_variance_target_step": kg.std(0).mean()})
             return loss
 
-        def local_loss(q_embed, k_embed, q_local, k_local, ids_q, ids_k, log=False):
+        def local_loss(q_embed, k_embed, q_local, k_local, ids_q, ids_k, k_row, log=False):
             st = {} if (log and extra is not None) else None
-            pos, _ = densecl_local_positives(q_embed, k_embed, q_local, k_local, ids_q, ids_k, self.lmbd_coordinate, metrics=st)
+            pos, _ = densecl_local_positives(q_embed, k_embed, q_local, k_local, ids_q, ids_k, self.lmbd_coordinate, metrics=st,
+                                             k_row=k_row, normalize_k=True)
             loss = queue_infonce(q_local, pos.reshape(-1), self.queue2, self.temp_local, stats=st)
             if st is not None:
                 nq = st["neg_quartiles"].mean(1)
@@ -751,14 +853,14 @@ class MODEL(nn.Module):
             return loss
 
         eq, lq, gq = query_features(img_a)
-        ek, lk, gk, pooled_k = key_features(img_b)
-        loss_global, loss_local = global_loss(gq, gk, log=True), local_loss(eq, ek, lq, lk, pix_a, pix_b, log=True)
+        ek, lk, gk, pooled_k, k_row = key_features(img_b)
+        loss_global, loss_local = global_loss(gq, gk, log=True), local_loss(eq, ek, lq, lk, pix_a, pix_b, k_row, log=True)
         update = (gk, pooled_k)
         if self.use_symmetrical_loss:
             eq2, lq2, gq2 = query_features(img_b)
-            ek2, lk2, gk2, pooled_k2 = key_features(img_a)
+            ek2, lk2, gk2, pooled_k2, k_row2 = key_features(img_a)
             loss_global = loss_global + global_loss(gq2, gk2)
-            loss_local = loss_local + local_loss(eq2, ek2, lq2, lk2, pix_b, pix_a)
+            loss_local = loss_local + local_loss(eq2, ek2, lq2, lk2, pix_b, pix_a, k_row2)
             if step % 2 == 0:
                 update = (gk2, pooled_k2)
         loss = (1 - self.lmbd_dense_loss) * loss_global + self.lmbd_dense_loss * loss_local

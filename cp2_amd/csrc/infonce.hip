@@ -698,6 +698,8 @@ CP2_API int cp2_rowkey_infonce_fwd(const float* rows, int RP, int64_t r_sn, int6
     if (NE > 0 && !extras) return CP2_ERR_NULL;
     if (R <= 0 || K <= 0 || RP <= 0 || nsplit <= 0 || NE < 0 || NE > 4 || !(temperature > 0.f)) return CP2_ERR_SHAPE;
     if (C != CH) return CP2_ERR_UNSUPPORTED;
+    const bool split_ready = precision == 3;      // keys_split already holds this queue's split (an earlier call wrote it)
+    if (split_ready) precision = 1;
     const int64_t ln_sk = lneg_row_major ? 1 : R, ln_sr = lneg_row_major ? K : 1;
     if (rowkey_use_small(R, K) && rowkey_small_rows_ok(rows, r_sn, r_sx, r_sc, keys)) {
         RowKeyArgs sa{rows, RP, r_sn, r_sx, r_sc, R, keys, K, extras, NE, 1.0f / temperature, 0,
@@ -723,11 +725,14 @@ CP2_API int cp2_rowkey_infonce_fwd(const float* rows, int RP, int64_t r_sn, int6
         __bf16* ks = static_cast<__bf16*>(keys_split);
         const bool pre = ks != nullptr && K % 16 == 0 && K <= (1 << 20) && cp2_aligned16(ks);
         if (pre) {      // the queue's hi / lo split once per call, then the LDS-DMA double-buffered kernel (rowkey_bf16x3.hip)
-            hipLaunchKernelGGL(keys_split_kernel, dim3(cp2_cdiv(K, 64)), dim3(256), 0, cp2_stream(stream), keys, K, ks);
-            int rc0 = cp2_launch_status();
-            if (rc0) return rc0;
+            if (!split_ready) {
+                hipLaunchKernelGGL(keys_split_kernel, dim3(cp2_cdiv(K, 64)), dim3(256), 0, cp2_stream(stream), keys, K, ks);
+                int rc0 = cp2_launch_status();
+                if (rc0) return rc0;
+            }
             return rowkey_bf16x3_dma_launch(a, ks, grid, wu, cp2_stream(stream));
         }
+        if (split_ready) return CP2_ERR_UNSUPPORTED;   // the caller's split cannot be used for this shape
         auto kfn = wu ? rowkey_fwd_bf16x3_kernel<true, false> : rowkey_fwd_bf16x3_kernel<false, false>;
         hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, BF_LDS);
         if (e_ != hipSuccess) return (int)e_;

@@ -567,13 +567,15 @@ def step_scalars(ins_loss, cnt_gt, extras, sample_scal, q_pos, k_pos, lmbd_dense
 
 # ---------------------------------------------------------------- a10 / a16
 class RowKeyResult:
-    __slots__ = ("loss", "lse", "loss_rows", "cnt_gt", "drows", "dE", "lnegT", "lneg")
+    __slots__ = ("loss", "lse", "loss_rows", "cnt_gt", "drows", "dE", "lnegT", "lneg", "ksplit")
 
 
 def rowkey_infonce(rows: torch.Tensor, row_layout: Tuple[int, int, int, int], R: int, keys: torch.Tensor,
                    extras: torch.Tensor, temperature: float, grad_scale: Optional[float],
                    drows_like: Optional[torch.Tensor] = None, want_lneg: bool = False,
-                   precision: str = "auto", presplit: bool = True, lneg_row_major: bool = False) -> RowKeyResult:
+                   precision: str = "auto", presplit: bool = True, lneg_row_major: bool = False,
+                   ksplit: Optional[torch.Tensor] = None, ksplit_ready: bool = False, lneg_out: Optional[torch.Tensor] = None,
+                   drows_out: Optional[torch.Tensor] = None) -> RowKeyResult:
     """InfoNCE of R row vectors against the queue `keys` [C,K] with `extras` [R,NE] prepended
     (column 0 = positive).  row_layout = (RP, stride_n, stride_x, stride_c): element (c, r) of
     `rows` lives at (r//RP)*stride_n + (r%RP)*stride_x + c*stride_c.
@@ -582,7 +584,11 @@ def rowkey_infonce(rows: torch.Tensor, row_layout: Tuple[int, int, int, int], R:
     precision: "f32" (exact fp32 on the f32-input MFMA), "bf16x3" (split-bf16, logits within 3e-5, ~3x faster when
     MFMA-bound), "bf16x6" (at most 32 rows: every operand as three bf16 parts, six products -- logits within 2e-7 of
     the exact fp32 value; measured no faster than "f32" at 32 x 65536, where the kernel waits for the queue stream, so
-    it is an option, not the default) or "auto" = bf16x3 from 1024 rows up (the DenseCL per-pixel case), f32 below."""
+    it is an option, not the default) or "auto" = bf16x3 from 1024 rows up (the DenseCL per-pixel case), f32 below.
+    For callers that walk the rows in several calls (the chunked DenseCL statistics): `ksplit` = the bf16x3 workspace to
+    use (4*C*K bf16; `ksplit_ready`: an earlier call on this stream already filled it for this queue), `lneg_out` = the
+    buffer (>= R*K floats) that receives the raw logits, `drows_out` = where the row gradient goes (a view in the rows'
+    layout)."""
     if precision not in ("auto", "f32", "bf16x3", "bf16x6"):
         raise ValueError(f"precision {precision!r}")
     if precision == "bf16x6" and R > 32:
@@ -605,13 +611,26 @@ def rowkey_infonce(rows: torch.Tensor, row_layout: Tuple[int, int, int, int], R:
     part_U = torch.empty((ns, C, R), dtype=torch.float32, device=dev) if want_grad else None
     out = RowKeyResult()
     out.lnegT = out.lneg = None          # raw logits rows.keys: lnegT [K,R] (key-major) or lneg [R,K] (row-major)
-    if want_lneg and lneg_row_major:
+    if want_lneg and lneg_out is not None:
+        if lneg_out.numel() < R * K or lneg_out.dtype != torch.float32 or not lneg_out.is_contiguous():
+            raise ValueError("rowkey_infonce: lneg_out must be a contiguous float32 buffer of at least R*K elements")
+        flat = lneg_out.reshape(-1)[:R * K]
+        out.lneg, out.lnegT = (flat.view(R, K), None) if lneg_row_major else (None, flat.view(K, R))
+    elif want_lneg and lneg_row_major:
         out.lneg = torch.empty((R, K), dtype=torch.float32, device=dev)
     elif want_lneg:
         out.lnegT = torch.empty((K, R), dtype=torch.float32, device=dev)
     lbuf = out.lneg if out.lneg is not None else out.lnegT
     # bf16x3: the queue's hi/lo split in both layouts, written once per call by a prep kernel (4*C*K bf16)
-    ksplit = torch.empty(4 * C * K, dtype=torch.bfloat16, device=dev) if (prec == 1 and R > 64 and K % 8 == 0 and presplit) else None
+    if not (prec == 1 and R > 64 and K % 8 == 0 and presplit):
+        ksplit, ksplit_ready = None, False
+    elif ksplit is None:
+        ksplit, ksplit_ready = torch.empty(4 * C * K, dtype=torch.bfloat16, device=dev), False
+    elif ksplit.numel() < 4 * C * K or ksplit.dtype != torch.bfloat16:
+        raise ValueError("rowkey_infonce: ksplit must hold 4*C*K bfloat16")
+    if ksplit_ready:
+        prec = 3
+    out.ksplit = ksplit
     if not rows.is_cuda or rows.dtype != torch.float32:
         raise _lib.Cp2LibraryError("rowkey_infonce: rows must be a float32 GPU tensor")
     _profile("rowkey_fwd" if R <= 32 else "rowkey_fwd_rows")
@@ -626,14 +645,84 @@ def rowkey_infonce(rows: torch.Tensor, row_layout: Tuple[int, int, int, int], R:
     out.loss = torch.empty((), dtype=torch.float32, device=dev)
     out.drows = out.dE = None
     if want_grad:
-        out.drows = torch.empty_like(rows if drows_like is None else drows_like)
+        out.drows = drows_out if drows_out is not None else torch.empty_like(rows if drows_like is None else drows_like)
         out.dE = torch.empty((R, NE), dtype=torch.float32, device=dev)
     rc = lib.cp2_rowkey_infonce_finalize(part_m.data_ptr(), part_s.data_ptr(), part_cnt.data_ptr(), _opt(part_U, "part_U"),
                                          ns, extras.data_ptr(), NE, float(temperature),
                                          float(grad_scale if want_grad else 0.0), R, RP, sn, sx, sc, out.lse.data_ptr(),
-                                         out.loss_rows.data_ptr(), out.cnt_gt.data_ptr(), _opt(out.drows, "drows"),
+                                         out.loss_rows.data_ptr(), out.cnt_gt.data_ptr(),
+                                         None if out.drows is None else out.drows.data_ptr(),
                                          _opt(out.dE, "dE"), out.loss.data_ptr(), C, _stream())
     _lib.check(rc, "cp2_rowkey_infonce_finalize")
+    return out
+
+
+# ---------------------------------------------------------------- a16: DenseCL positive selection (T18)
+class DenseclMatch:
+    __slots__ = ("best", "pos", "kvec", "counts")
+
+
+def _embed_view(t: torch.Tensor, name: str) -> torch.Tensor:
+    """A backbone feature map [B,C,h,w] / [B,C,P] in a form cp2_densecl_match reads in place: fp32 with any uniform pixel
+    stride, or bf16 with the channel index fastest (channels-last) -- anything else is re-laid once."""
+    if not t.is_cuda:
+        raise _lib.Cp2LibraryError(f"{name} is on {t.device}; cp2_amd ops run on the GPU only")
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError(f"{name}: float32 or bfloat16 expected, got {t.dtype}")
+    if t.dim() == 4:
+        _, _, h, w = t.shape
+        uniform = h == 1 or t.stride(2) == w * t.stride(3)
+        cl_ok = t.stride(1) == 1 and t.stride(3) % 8 == 0 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0
+        if not uniform or (t.dtype == torch.bfloat16 and not cl_ok):
+            t = t.contiguous(memory_format=torch.channels_last)
+        return t
+    if t.dim() != 3:
+        raise ValueError(f"{name}: [B,C,h,w] or [B,C,P] expected")
+    if t.dtype == torch.bfloat16 and not (t.stride(1) == 1 and t.stride(2) % 8 == 0 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0):
+        t = t.transpose(1, 2).contiguous().transpose(1, 2)
+    return t
+
+
+def densecl_match(q_embed: torch.Tensor, k_embed: torch.Tensor, q_local: torch.Tensor, k_local: torch.Tensor,
+                  ids_q: Optional[torch.Tensor] = None, ids_k: Optional[torch.Tensor] = None, lmbd_coordinate: float = 0.0,
+                  k_row: Optional[torch.Tensor] = None, normalize_k: bool = True, want_kvec: bool = True,
+                  want_metrics: bool = False) -> DenseclMatch:
+    """Positive of every query pixel of the DenseCL local loss (reference builder.py:818-864) in one launch.
+    q_embed / k_embed: backbone features [B,CE,h,w] or [B,CE,P], bf16 (channels-last) or fp32, raw (normalize_k=True) or
+    already channel-normalised (normalize_k=False); q_local / k_local: fp32 [B,128,P] unit vectors; ids: int64 [B,P].
+    k_row (int64 [B]): sample n's key side is row k_row[n] of k_embed / k_local.  Returns best (int32 [B,P]), pos [B,P],
+    kvec [B,128,P] = d pos / d q_local (want_kvec), counts int32 [groups,2] (want_metrics: overlapping pixels, hits)."""
+    lib = _lib.load()
+    qe, ke = _embed_view(q_embed, "q_embed"), _embed_view(k_embed, "k_embed")
+    if qe.dtype != ke.dtype:
+        raise TypeError("densecl_match: q_embed and k_embed must have the same dtype")
+    B, CE, P, qsn, qsc, qsp = _feat_strides(qe)
+    B2, CE2, P2, ksn, ksc, ksp = _feat_strides(ke)
+    CL = q_local.shape[1]
+    if (B2, CE2, P2) != (B, CE, P) or tuple(q_local.shape) != (B, CL, P) or tuple(k_local.shape) != (B, CL, P):
+        raise ValueError("densecl_match: feature shapes do not agree")
+    if (ids_q is None) != (ids_k is None):
+        raise ValueError("densecl_match: ids_q and ids_k come together")
+    if ids_q is not None and (ids_q.numel() != B * P or ids_k.numel() != B * P):
+        raise ValueError("densecl_match: ids must hold B*P elements")
+    if k_row is not None and (k_row.numel() != B or k_row.dtype != torch.int64):
+        raise ValueError("densecl_match: k_row must hold B int64 indices")
+    dev = q_local.device
+    out = DenseclMatch()
+    out.best = torch.empty((B, P), dtype=torch.int32, device=dev)
+    out.pos = torch.empty((B, P), dtype=torch.float32, device=dev)
+    out.kvec = torch.empty((B, CL, P), dtype=torch.float32, device=dev) if want_kvec else None
+    out.counts = torch.empty((B * ((P + 31) // 32), 2), dtype=torch.int32, device=dev) if want_metrics else None
+    lm = float(np.float32(lmbd_coordinate))
+    one_minus = float(np.float32(1.0 - lmbd_coordinate))      # the reference's python `1 - self.lmbd_coordinate` (builder.py:853)
+    _profile("densecl_match")
+    rc = lib.cp2_densecl_match(qe.data_ptr(), ke.data_ptr(), int(qe.dtype == torch.bfloat16), qsn, qsc, qsp, ksn, ksc, ksp,
+                               _opt(k_row, "k_row", torch.int64), _dev(q_local, "q_local", torch.float32),
+                               _dev(k_local, "k_local", torch.float32), _opt(ids_q, "ids_q", torch.int64),
+                               _opt(ids_k, "ids_k", torch.int64), lm, one_minus, int(normalize_k), int(want_metrics),
+                               out.best.data_ptr(), out.pos.data_ptr(), _opt(out.kvec, "kvec"), _opt(out.counts, "counts"),
+                               B, CE, CL, P, _stream())
+    _lib.check(rc, "cp2_densecl_match")
     return out
 
 

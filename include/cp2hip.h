@@ -184,7 +184,9 @@ int cp2_step_scalars(const float* ins_loss, const int32_t* cnt_gt, const float* 
  * precision 1: split-bf16 (hi*hi + hi*lo + lo*hi on bf16 MFMA, fp32 accumulate; logits within 3e-5) -- used when
  *              R > 64, otherwise the f32 kernel runs regardless.  keys_split: NULL, or a workspace of 4*C*K bf16
  *              (16-byte aligned, K % 8 == 0) that receives the hi/lo split of the queue in both layouts once per call;
- *              with it the main kernel fills LDS by 16-byte copies instead of converting in every row block. */
+ *              with it the main kernel fills LDS by 16-byte copies instead of converting in every row block;
+ * precision 3: as 1, but keys_split already holds the split of this queue (written by an earlier precision-1 call on the
+ *              same stream): the prep launch is skipped -- for callers that walk the rows in several calls. */
 int cp2_rowkey_num_splits(int R, int K);
 int cp2_rowkey_infonce_fwd(const float* rows, int RP, int64_t r_sn, int64_t r_sx, int64_t r_sc, int R,
                            const float* keys, int K, const float* extras, int NE, float temperature,
@@ -235,6 +237,29 @@ int cp2_dense_infonce_bwd(const float* q_dense, const float* k_dense, const floa
                           const float* sample_scal, float grad_scale, float* g_dense, float* split_ws,
                           int negative_mode, float negative_scale, const float* negative_center, int B, int C,
                           int P, void* stream);
+
+/* ---- a16: DenseCL positive selection (T18) ---------------- builder.py:818-864
+ * Replaces: einsum("ncx,ncy->nxy", q_embed, k_embed).max(dim=2)[1] (:818-821), the local-similarity einsum and its
+ * gather at that index (:824-835), get_correlation_map + the coordinate mix (:839-855) and the matching-positives rate
+ * (:857-864) -- three b x S^2 x S^2 maps in the reference, none here.
+ *   best_idx[n,x] = argmax_y <q_embed[n,:,x], k_embed[n,:,y]> (first maximum); with normalize_k the key vector is divided
+ *                   by max(|k_embed[n,:,y]|, 1e-12) first, i.e. the inputs may be the RAW backbone features (the query
+ *                   norm cannot change the arg-max); normalize_k = 0: the key vectors are unit vectors already;
+ *   pos[n,x]      = <q_local[n,:,x], k_local[n,:,best]>; where id_q[n,x] occurs among id_k[n,:] and lmbd_coordinate > 0:
+ *                   pos * one_minus_lmbd + lmbd_coordinate * sum_{y: id_k[n,y] == id_q[n,x]} <q_local[n,:,x], k_local[n,:,y]>;
+ *   kvec[n,:,x]   = d pos[n,x] / d q_local[n,:,x] (NULL: not wanted);
+ *   counts[2*i + {0,1}], i < B * ceil(P/32) (want_metrics; NULL otherwise): per workgroup, the number of query pixels
+ *                   with an id match, and of those whose arg-max of the LOCAL similarity is their first id match.
+ * q_embed / k_embed: element (n, c, p) at n*sn + c*sc + p*sp; embed_bf16 != 0: bf16, channels-last (sc == 1), CE % 64 == 0,
+ * 16-byte aligned rows (bf16 MFMA: exact products, fp32 accumulation); else fp32 with any strides (f32-input MFMA).
+ * k_row: NULL, or int64 [B]: sample n's key side is row k_row[n] of k_embed / k_local (the shuffle-BN un-shuffle index,
+ * builder.py:649, without a gather launch); ids stay in sample order.  q_local / k_local: fp32 [B,CL,P] unit vectors,
+ * CL = 128; ids_q / ids_k: int64 [B,P] or both NULL; P <= 4096. */
+int cp2_densecl_match(const void* q_embed, const void* k_embed, int embed_bf16, int64_t qe_sn, int64_t qe_sc, int64_t qe_sp,
+                      int64_t ke_sn, int64_t ke_sc, int64_t ke_sp, const int64_t* k_row, const float* q_local,
+                      const float* k_local, const int64_t* ids_q, const int64_t* ids_k, float lmbd_coordinate,
+                      float one_minus_lmbd, int normalize_k, int want_metrics, int32_t* best_idx, float* pos, float* kvec,
+                      int32_t* counts, int B, int CE, int CL, int P, void* stream);
 
 /* ---- a15: logging quantiles without a sort ---------------- tools/correlation_mapping.py:16-53, builder.py:1399-1406
  * out[j, r] = torch.nanquantile(kept elements of row r, q[j]) with linear interpolation (exact order statistics by

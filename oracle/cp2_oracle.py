@@ -403,6 +403,22 @@ def densecl_local_loss(q_embed, k_embed, q_local, k_local, q_pixel_ids, k_pixel_
     return loss, pos, neg, best
 
 
+def densecl_matching_rate(q_local, k_local, q_pixel_ids, k_pixel_ids):
+    """builder.py:856-864, as evidently intended: over the query pixels whose id occurs in the key map, how often the
+    arg-max of the local similarity row is the arg-max (= first match) of the id-equality row; -1 without overlap.
+    The reference's own expression cannot be pinned: `corr_map[overlap_pixels, :].max(dim=2)` (:861) indexes dim 2 of a
+    2-D tensor and raises IndexError whenever there is overlap (see tests/golden/make_goldens.py
+    run_densecl_overlap_case)."""
+    corr = correlation_map(q_pixel_ids, k_pixel_ids)["corr_map"]
+    overlap = corr.sum(-1) > 0
+    if int(overlap.sum()) == 0:
+        return -1.0
+    local_sim = torch.einsum("ncx,ncy->nxy", q_local, k_local)
+    corr_max = corr[overlap].float().argmax(dim=1)
+    sim_max = local_sim[overlap].argmax(dim=1)
+    return float((corr_max == sim_max).float().mean())
+
+
 def queue_infonce(rows, pos, queue, temperature):
     """The rows-vs-queue InfoNCE on its own (T19): mean_r [lse_r - pos_r/T]."""
     return contrastive_head(pos.reshape(-1, 1), rows @ queue, temperature)

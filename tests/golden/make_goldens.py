@@ -314,6 +314,63 @@ def run_densecl_case(name, b, h, w, K, stride, seed, lmbd_coordinate=0.0, symmet
     print(f"{name}: loss={float(loss):.6f} global={float(glob['__ret']):.6f} local={float(loc['__ret']):.6f}")
 
 
+def run_densecl_overlap_case(name, b, h, w, K, stride, seed, lmbd_coordinate):
+    """DenseCL local positives WITH id overlap between the two views (the coordinate mix of builder.py:838-855).
+    The reference cannot finish such a step: builder.py:861 calls `.max(dim=2)` on the 2-D tensor
+    `corr_map[overlap_pixels, :]` and raises IndexError as soon as one pixel id occurs in both down-sampled maps
+    (which is why the other DenseCL fixtures, made from a whole forward pass, contain no overlap).  The mix itself is
+    computed BEFORE that line, so this fixture records compute_local_loss's locals at the moment the reference raises:
+    the inputs, pos_global_k_idx, overlap_pixels and pos_local after the mix."""
+    torch.manual_seed(seed)
+    gen = torch.Generator().manual_seed(seed)
+    m = blank_model(K, backbone_stride=stride, temp_local=0.2, lmbd_dense=0.5, pretrain_type=PretrainType.PROPOSED_V2,
+                    lmbd_coordinate=lmbd_coordinate)
+    m.encoder_q, m.encoder_k = DenseEnc(stride), DenseEnc(stride)
+    for pq, pk in zip(m.encoder_q.parameters(), m.encoder_k.parameters()):
+        pk.data.copy_(pq.data + 0.01 * torch.randn_like(pq))
+        pk.requires_grad = False
+    inp = synth_inputs(b, h, w, gen)
+    # second view = the first view's id grid shifted by whole strides (centre taps coincide where the crops overlap);
+    # sample 1 additionally repeats ids (two key pixels carry the id of one query pixel)
+    big = torch.arange(1, 4 * h * w + 1).reshape(2 * h, 2 * w)
+    pb = []
+    for n in range(b):
+        dy, dx = stride * (1 + n % 2), stride * (2 - n % 2)
+        crop = (big[dy:dy + h, dx:dx + w] + n * 4 * h * w).clone()
+        if n % 2:
+            crop[:, w // 2:] = crop[:, : w - w // 2]
+        pb.append(crop)
+    inp["pixel_ids_b"] = torch.stack(pb)
+    inp["region_ids_b"] = inp["pixel_ids_b"].clone()
+    code = [c for c in ref.MODEL.forward_densecl.__code__.co_consts if getattr(c, "co_name", "") == "compute_local_loss"][0]
+    qcode = [c for c in ref.MODEL.forward_densecl.__code__.co_consts if getattr(c, "co_name", "") == "get_query_features"][0]
+    grabbed = {}
+
+    def prof(frame, event, arg):
+        if event == "return" and frame.f_code is code and "loc" not in grabbed:
+            grabbed["loc"], grabbed["returned"] = dict(frame.f_locals), arg is not None
+        if event == "return" and frame.f_code is qcode and "q" not in grabbed:
+            grabbed["q"] = dict(frame.f_locals)
+    sys.setprofile(prof)
+    raised = None
+    try:
+        m.forward_densecl(visualize=False, step=0, new_epoch=False, **inp)
+    except IndexError as e:
+        raised = str(e)
+    finally:
+        sys.setprofile(None)
+    loc = grabbed["loc"]
+    assert raised is not None and not grabbed["returned"], "the reference was expected to raise at builder.py:861"
+    assert int(loc["overlap_pixels"].sum()) > 0
+    rec = {"q_embed": np_(loc["q_embed"]), "k_embed": np_(loc["k_embed"]), "q_local": np_(grabbed["q"]["q_local"]),
+           "k_local": np_(loc["k_local"]), "q_pixel_ids": np_(loc["q_pixel_ids"]), "k_pixel_ids": np_(loc["k_pixel_ids"]),
+           "pos_global_k_idx": np_(loc["pos_global_k_idx"]), "overlap_pixels": np_(loc["overlap_pixels"]),
+           "pos_local": np_(loc["pos_local"]), "cfg": np.array([b, h, w, K, stride], dtype=np.int64),
+           "cfg_f": np.array([m.temp_global, m.temp_local, m.lmbd_dense_loss, lmbd_coordinate], dtype=np.float64)}
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print(f"{name}: reference raised {raised!r}; {int(loc['overlap_pixels'].sum())} overlapping query pixels recorded")
+
+
 def run_queue_ema_cases():
     rec = {}
     torch.manual_seed(7)
@@ -407,6 +464,7 @@ def main():
     # ... and the symmetric PROPOSED_V2 pass with coordinate mixing (builder.py:944-972)
     run_densecl_case("densecl_v2_symmetric", b=2, h=96, w=96, K=64, stride=16, seed=8, lmbd_coordinate=0.3,
                      symmetric=True, step=0)
+    run_densecl_overlap_case("densecl_coord_overlap", b=2, h=96, w=96, K=64, stride=16, seed=9, lmbd_coordinate=0.3)
     torch.distributed.destroy_process_group()
 
 

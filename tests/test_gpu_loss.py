@@ -477,6 +477,142 @@ def test_densecl_local_positives_and_losses_golden(golden_dir, name):
     assert torch.isfinite(ql.grad).all() and float(ql.grad.abs().max()) > 0
 
 
+def test_densecl_coordinate_mix_golden(golden_dir):
+    """cp2_densecl_match on the reference's recorded tensors WITH id overlap (the coordinate mix, builder.py:838-855;
+    fixture taken at the point where the reference's :861 raises): indices exact, mixed positives to 3e-6."""
+    from cp2_amd import builder
+    g = load(golden_dir, "densecl_coord_overlap")
+    lc, b = float(g["cfg_f"][3]), g["q_local"].shape[0]
+    st = {}
+    pos, best = builder.densecl_local_positives(G(g["q_embed"]), G(g["k_embed"]), G(g["q_local"]), G(g["k_local"]),
+                                                G(g["q_pixel_ids"]).reshape(b, -1), G(g["k_pixel_ids"]).reshape(b, -1), lc,
+                                                metrics=st)
+    assert np.array_equal(best.cpu().numpy(), g["pos_global_k_idx"])
+    assert_close(pos, g["pos_local"], 3e-6, what="pos_local (mixed)")
+    want = O.densecl_matching_rate(torch.from_numpy(g["q_local"]), torch.from_numpy(g["k_local"]),
+                                   torch.from_numpy(g["q_pixel_ids"]), torch.from_numpy(g["k_pixel_ids"]))
+    assert abs(float(st["matching_positives_rate"]) - want) < 1e-6
+
+
+def _match_case(B, P, CE, seed, dup=True):
+    """Random DenseCL features whose backbone similarities are well separated + id maps with overlap and repeated ids."""
+    g = torch.Generator().manual_seed(seed)
+    qe, ke = torch.randn(B, CE, P, generator=g), torch.randn(B, CE, P, generator=g)
+    ql = torch.nn.functional.normalize(torch.randn(B, 128, P, generator=g), dim=1)
+    kl = torch.nn.functional.normalize(torch.randn(B, 128, P, generator=g), dim=1)
+    ids_q = torch.stack([torch.randperm(4 * P, generator=g)[:P] + 1 + n * 10 * P for n in range(B)])
+    ids_k = torch.stack([torch.randperm(4 * P, generator=g)[:P] + 1 + n * 10 * P for n in range(B)])
+    ids_k[:, : P // 3] = ids_q[:, torch.randperm(P, generator=g)[: P // 3]]          # a third of the key pixels match
+    if dup:
+        ids_k[:, P // 3: P // 3 + 5] = ids_k[:, :5]                                   # five ids occur twice among the keys
+    return qe, ke, ql, kl, ids_q, ids_k
+
+
+def _match_oracle(qe, ke, ql, kl, ids_q, ids_k, lmbd):
+    """oracle positives + d sum(pos * w) / d q_local, with the top-2 gap of the backbone similarity per query pixel."""
+    qn, kn = torch.nn.functional.normalize(qe.double(), dim=1), torch.nn.functional.normalize(ke.double(), dim=1)
+    sim = torch.einsum("ncx,ncy->nxy", qn, kn)
+    top2 = sim.topk(2, dim=2).values
+    q = ql.clone().requires_grad_(True)
+    queue2 = torch.nn.functional.normalize(torch.randn(128, 8, generator=torch.Generator().manual_seed(1)), dim=0)
+    _, pos, _, best = O.densecl_local_loss(qn.float(), kn.float(), q, kl, ids_q, ids_k, queue2, lmbd_coordinate=lmbd)
+    w = torch.linspace(0.5, 1.5, pos.numel()).reshape(pos.shape)
+    (pos * w).sum().backward()
+    return pos.detach(), best, q.grad, w, (top2[..., 0] - top2[..., 1]).float(), sim.argmax(2)
+
+
+@pytest.mark.parametrize("B,P,CE,form,lmbd", [(3, 36, 2048, "f32_nchw", 0.3), (2, 196, 2048, "bf16_cl", 0.3), (2, 196, 512, "f32_cl", 0.0),
+                                              (2, 300, 256, "bf16_cl", 0.25), (1, 300, 128, "f32_nchw", 0.5), (4, 49, 2048, "bf16_cl4", 0.0)])
+def test_densecl_match_vs_oracle(B, P, CE, form, lmbd):
+    """cp2_densecl_match (T18, builder.py:818-864) on raw backbone features in every layout it reads in place -- fp32
+    NCHW / channels-last, bf16 channels-last 3-D and 4-D -- with a key-row permutation, overlapping and repeated ids:
+    arg-max index equal to the fp64 arg-max wherever the top-2 gap exceeds 1e-5 (elsewhere the chosen similarity is within
+    1e-5 of the maximum), positives to 3e-6, d pos / d q_local to 3e-6, the matching-positives counts exact."""
+    from cp2_amd import builder
+    qe, ke, ql, kl, ids_q, ids_k = _match_case(B, P, CE, seed=B * 1000 + P + CE)
+    if form.startswith("bf16"):
+        qe, ke = qe.bfloat16().float(), ke.bfloat16().float()           # the values a bf16 backbone hands over
+    pos_w, best_w, grad_w, w, gap, best64 = _match_oracle(qe, ke, ql, kl, ids_q, ids_k, lmbd)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(5))
+    k_row = torch.argsort(perm)                                         # sample n's key side sits at row k_row[n]
+    ke_s, kl_s = ke[perm], kl[perm]
+
+    def dev_embed(x):
+        x = x.to(DEV)
+        if form == "f32_nchw":
+            return x.contiguous()
+        if form == "f32_cl":
+            return x.transpose(1, 2).contiguous().transpose(1, 2)
+        if form == "bf16_cl":
+            return x.bfloat16().transpose(1, 2).contiguous().transpose(1, 2)
+        s = int(round(P ** 0.5))
+        return x.bfloat16().reshape(B, CE, s, s).contiguous(memory_format=torch.channels_last)
+    q = ql.to(DEV).requires_grad_(True)
+    st = {}
+    pos, best = builder.densecl_local_positives(dev_embed(qe), dev_embed(ke_s), q, kl_s.to(DEV), ids_q.to(DEV), ids_k.to(DEV), lmbd,
+                                                metrics=st, k_row=k_row.to(DEV), normalize_k=True)
+    (pos * w.to(DEV)).sum().backward()
+    best = best.cpu()
+    clear = gap > 1e-5
+    assert torch.equal(best[clear], best64[clear]), "arg-max differs where the top-2 gap is clear"
+    # rows whose arg-max is decided inside rounding noise: whichever was chosen must be a maximum to 1e-5
+    sim = torch.einsum("ncx,ncy->nxy", torch.nn.functional.normalize(qe, dim=1), torch.nn.functional.normalize(ke, dim=1))
+    chosen = sim.gather(2, best.unsqueeze(2)).squeeze(2)
+    assert float((sim.max(2).values - chosen).max()) <= 1e-5
+    same = best == best_w
+    assert same.float().mean() > 0.99
+    assert_close(pos.cpu()[same], pos_w[same], 3e-6, what="pos")
+    samec = same.unsqueeze(1).expand_as(grad_w)
+    assert_close(q.grad.cpu()[samec], grad_w[samec], 3e-6, what="d pos / d q_local")
+    want = O.densecl_matching_rate(ql, kl, ids_q, ids_k)
+    assert abs(float(st["matching_positives_rate"]) - want) <= 1.0 / max(1, int((ids_q[:, :, None] == ids_k[:, None, :]).any(-1).sum())) + 1e-6
+
+
+def test_densecl_match_without_ids_and_normalised_inputs():
+    """No id maps (plain DenseCL) and inputs that are unit vectors already (normalize_k=False): the golden path's form."""
+    from cp2_amd import ops
+    qe, ke, ql, kl, _, _ = _match_case(2, 64, 256, seed=3)
+    qn, kn = torch.nn.functional.normalize(qe, dim=1), torch.nn.functional.normalize(ke, dim=1)
+    res = ops.densecl_match(qn.to(DEV), kn.to(DEV), ql.to(DEV), kl.to(DEV), normalize_k=False, want_kvec=True)
+    sim = torch.einsum("ncx,ncy->nxy", qn.double(), kn.double())
+    top2 = sim.topk(2, dim=2).values
+    clear = (top2[..., 0] - top2[..., 1]) > 1e-5
+    best = res.best.cpu().long()
+    assert torch.equal(best[clear], sim.argmax(2)[clear])
+    want_k = torch.gather(kl, 2, best.unsqueeze(1).expand(-1, 128, -1))
+    assert torch.equal(res.kvec.cpu(), want_k)                       # the gathered key vectors, bit for bit
+    assert_close(res.pos, (ql * want_k).sum(1), 2e-6, what="pos")
+
+
+def test_queue_infonce_chunked_statistics_equal_one_shot(monkeypatch):
+    """The rank-0 DenseCL score statistics (reference builder.py:875-886) walked in groups of samples through one re-used
+    logit buffer (_queue_infonce_chunked) against the one-shot form that materialises every row's logits: per-row
+    quartiles and means bit for bit (same kernels, same per-row arithmetic), loss and gradients to 1e-6."""
+    from cp2_amd import builder
+    g = torch.Generator(DEV).manual_seed(11)
+    b, C, S2, K = 6, 128, 196, 4096                                   # 1176 rows: the bf16x3 kernel, as at 32 x 196
+    rows = torch.nn.functional.normalize(torch.randn(b, C, S2, device=DEV, generator=g), dim=1)
+    queue = torch.nn.functional.normalize(torch.randn(C, K, device=DEV, generator=g), dim=0)
+    pos = torch.rand(b * S2, device=DEV, generator=g)
+    out = {}
+    for tag, limit in (("one", 1 << 40), ("chunked", 2 * S2 * K * 4)):
+        monkeypatch.setattr(builder, "STATS_CHUNK_BYTES", limit)
+        r = rows.clone().requires_grad_(True)
+        p = pos.clone().requires_grad_(True)
+        st = {}
+        loss = builder.queue_infonce(r, p, queue, 0.2, stats=st)
+        loss.backward()
+        out[tag] = (loss.detach(), r.grad, p.grad, st["neg_mean"], st["neg_quartiles"])
+    a, c = out["one"], out["chunked"]
+    assert torch.equal(a[4], c[4]) and torch.equal(a[3], c[3])
+    assert_close(c[0], a[0], 1e-6, what="loss")
+    assert_close(c[1], a[1], 1e-9, 1e-6, what="d rows")
+    assert_close(c[2], a[2], 1e-9, 1e-6, what="d pos")
+    lneg = torch.einsum("ncx,ck->nxk", rows, queue).reshape(b * S2, K)
+    want = torch.quantile(lneg, torch.tensor([0.25, 0.5, 0.75], device=DEV), dim=1)
+    assert_close(c[4], want, 1e-4, what="quartiles vs torch.quantile of an fp32 product (bf16x3 logits: 3e-5)")
+
+
 def test_densecl_symmetric_golden(golden_dir):
     """PROPOSED_V2 symmetric pass (reference builder.py:944-972): both passes' global and local losses on the recorded
     tensors, summed as the reference does."""

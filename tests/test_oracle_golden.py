@@ -223,6 +223,25 @@ def test_densecl_golden(golden_dir, name):
     assert np.array_equal(qa2.numpy(), g["queue2_after"]) and ptr2 == int(g["ptr2_after"])
 
 
+def test_densecl_coordinate_mix_golden(golden_dir):
+    """The coordinate mix of builder.py:838-855 WITH id overlap: the reference's own locals at the point where its
+    :861 raises (make_goldens.run_densecl_overlap_case) -- arg-max indices equal, mixed positives to 1e-6."""
+    g = load(golden_dir, "densecl_coord_overlap")
+    lc = float(g["cfg_f"][3])
+    queue2 = torch.nn.functional.normalize(torch.randn(128, 64, generator=torch.Generator().manual_seed(0)), dim=0)
+    _, pos, _, best = O.densecl_local_loss(T(g["q_embed"]), T(g["k_embed"]), T(g["q_local"]), T(g["k_local"]),
+                                           T(g["q_pixel_ids"]), T(g["k_pixel_ids"]), queue2, lmbd_coordinate=lc)
+    assert int(g["overlap_pixels"].sum()) == 32
+    assert np.array_equal(best.numpy(), g["pos_global_k_idx"])
+    close(pos, g["pos_local"])
+    # without the mix the overlapping pixels would differ: the fixture does exercise it
+    _, plain, _, _ = O.densecl_local_loss(T(g["q_embed"]), T(g["k_embed"]), T(g["q_local"]), T(g["k_local"]),
+                                          T(g["q_pixel_ids"]), T(g["k_pixel_ids"]), queue2, lmbd_coordinate=0.0)
+    assert float((plain - pos).abs().max()) > 1e-3
+    rate = O.densecl_matching_rate(T(g["q_local"]), T(g["k_local"]), T(g["q_pixel_ids"]), T(g["k_pixel_ids"]))
+    assert 0.0 <= rate <= 1.0
+
+
 def test_sgd_restatement_matches_torch_sgd_on_cpu():
     """oracle.sgd_momentum_step against torch.optim.SGD itself (the optimizer the reference constructs, main.py:467-477)
     on CPU: three steps with momentum and weight decay, one parameter without gradient; <= 1 ulp."""
