@@ -18,6 +18,12 @@ main stream's wait for the side stream when --overlap selects one, and the expos
 averaging (step time minus the step time of a few extra steps under no_sync()) -- so that the first multi-GPU run explains
 its own scaling.  `host_issue_ms_per_step` is the time the CPU needs to enqueue a step: when it approaches `ms_per_step`
 the run was host-bound, not GPU-bound.  `--rehearse-collectives` runs the N > 1 code path with one rank over RCCL.
+
+`--workload cfg2|cfg4|cfg5` selects the BASELINE.json configuration (default cfg2 = configs[1], the one the metric is
+quoted on): cfg4 = configs[3] (ResNet-101 + dilated FCN head at output stride 8, 512x512, queue 131072, 8 img/GPU), cfg5 =
+configs[4] (DenseCL, scripts/10-11-densecl.sh: ResNet-50 backbone of configs/config_pretrain.py + DenseCL neck, per-pixel
+rows against queue2, no copy-paste mask).  `metric`, `config.workload`, `roofline` (that workload's dominant hand-written
+kernel) and `cpu_baseline` (the CPU port of the same step) are built from what actually ran.
 """
 import argparse
 import json
@@ -40,15 +46,28 @@ BF16_DENSE_PEAK_TFLOPS = 2500.0
 F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32: the f32 vector rate (same guide, "Matrix cores")
 
 
+# BASELINE.json configs the bench can run end to end on one GPU (reference: configs/*.py, scripts/10-11-densecl.sh:33-52)
+WORKLOADS = {
+    "cfg2": dict(label="BASELINE configs[1]", config="config_pretrain_r50_fcn.py", img=224, queue=65536, batch=32, densecl=False,
+                 cpu=(32, 5, 2)),
+    "cfg4": dict(label="BASELINE configs[3]", config="config_pretrain_r101_d8.py", img=512, queue=131072, batch=8, densecl=False,
+                 cpu=(8, 2, 1)),
+    "cfg5": dict(label="BASELINE configs[4]", config="config_pretrain.py", img=224, queue=65536, batch=32, densecl=True,
+                 cpu=(8, 2, 1)),
+}
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=50)
     p.add_argument("--warmup", type=int, default=10)
-    p.add_argument("--batch-per-gpu", type=int, default=32)
-    p.add_argument("--img", type=int, default=224)
-    p.add_argument("--queue", type=int, default=65536)
-    p.add_argument("--config", default=os.path.join(ROOT, "configs", "config_pretrain_r50_fcn.py"))
+    p.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS),
+                   help="BASELINE.json configuration: cfg2 = configs[1] (the metric's), cfg4 = configs[3], cfg5 = configs[4] (DenseCL)")
+    p.add_argument("--batch-per-gpu", type=int, default=None, help="default: the workload's (32; cfg4: 8)")
+    p.add_argument("--img", type=int, default=None, help="default: the workload's (224; cfg4: 512)")
+    p.add_argument("--queue", type=int, default=None, help="default: the workload's (65536; cfg4: 131072)")
+    p.add_argument("--config", default=None, help="model config file; default: the workload's")
     p.add_argument("--amp", default="bf16", choices=["bf16", "none"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--gemm-1x1", default="on", choices=["on", "off"],
@@ -59,9 +78,13 @@ def parse():
                    help="optimizer step as one HIP launch on the flat parameter buffer (off: torch.optim.SGD) (A/B)")
     p.add_argument("--fused-bn", default="on", choices=["on", "off"], help="encoder fast path: fused BN(+add)(+ReLU) kernels (A/B)")
     p.add_argument("--overlap", default="auto", choices=["auto", "gather", "on", "off"],
-                   help="side HIP stream for the key branch: off = everything in order on one stream (auto: measured fastest, also "
-                        "with the collectives of N > 1), gather = EMA + shuffle exchange + key gather on a side stream, on = the key "
-                        "encoder too")
+                   help="side HIP stream for the key branch: off = everything in order on one stream, gather = EMA + shuffle "
+                        "exchange + key gather on a side stream (north_star's form), on = the key encoder too; auto = one stream at "
+                        "N = 1, and at N > 1 MEASURED: a few steps of each of off / gather after the warm-up, the faster one (max over "
+                        "ranks) runs the timed region and both numbers go into `comm`")
+    p.add_argument("--calib-steps", type=int, default=6, help="--overlap auto at N > 1: steps per candidate (>= 5)")
+    p.add_argument("--timeout", type=float, default=120.0, help="process-group timeout in seconds (N > 1); the hang watchdog "
+                   "names the exchange step that did not complete at 0.8 x this and exits non-zero")
     p.add_argument("--shuffle-exchange", default="all_to_all", choices=["all_to_all", "all_gather"],
                    help="shuffle-BN rows by all-to-all (only the rows a rank keeps travel) or the reference's all-gather form (A/B)")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
@@ -76,10 +99,23 @@ def parse():
                         "gradient buffer; what cp2_amd.main uses) or by torch's DistributedDataParallel (one copy launch per parameter)")
     p.add_argument("--nosync-steps", type=int, default=10,
                    help="N > 1: extra steps under DDP.no_sync() after the timed region (exposed all-reduce time); 0 = skip")
-    p.add_argument("--cpu-batch", type=int, default=32, help="CPU baseline: images per step (BASELINE.md section 3: the same b)")
-    p.add_argument("--cpu-steps", type=int, default=5, help="CPU baseline: timed steps (after --cpu-warmup)")
-    p.add_argument("--cpu-warmup", type=int, default=2)
-    return p.parse_args()
+    p.add_argument("--cpu-batch", type=int, default=None, help="CPU baseline: images per step (default: cfg2 32 = the same b; cfg4 8; cfg5 8)")
+    p.add_argument("--cpu-steps", type=int, default=None, help="CPU baseline: timed steps after --cpu-warmup (default: cfg2 5; cfg4 / cfg5 2)")
+    p.add_argument("--cpu-warmup", type=int, default=None, help="default: cfg2 2; cfg4 / cfg5 1")
+    args = p.parse_args()
+    wl = WORKLOADS[args.workload]
+    # a line is labelled with a BASELINE configuration only when every size-defining argument is that configuration's
+    args.as_baseline = all(v is None for v in (args.batch_per_gpu, args.img, args.queue, args.config))
+    args.batch_per_gpu = wl["batch"] if args.batch_per_gpu is None else args.batch_per_gpu
+    args.img = wl["img"] if args.img is None else args.img
+    args.queue = wl["queue"] if args.queue is None else args.queue
+    args.config = os.path.join(ROOT, "configs", wl["config"]) if args.config is None else args.config
+    cb, cs, cw = wl["cpu"]
+    args.cpu_batch = cb if args.cpu_batch is None else args.cpu_batch
+    args.cpu_steps = cs if args.cpu_steps is None else args.cpu_steps
+    args.cpu_warmup = cw if args.cpu_warmup is None else args.cpu_warmup
+    args.densecl = wl["densecl"]
+    return args
 
 
 def _free_port() -> int:
@@ -138,7 +174,7 @@ def physical_cores() -> int:
         return os.cpu_count() or 1
 
 
-def count_flops_per_image(torch, model, batch):
+def count_flops_per_image(torch, model, batch, densecl=False):
     """FLOPs of one step (q forward+backward, k forward, loss GEMMs excluded) via torch's flop counter.  The counter only
     sees ATen operators, so the pass runs with every convolution on the ATen path (the product path sends the 1x1 and
     k x k weight gradients through cp2_wgrad1x1 / cp2_wgrad_conv, which it would not count)."""
@@ -146,13 +182,20 @@ def count_flops_per_image(torch, model, batch):
     from cp2_amd.encoder import Conv2d
     saved = (Conv2d.cpp_nodes, Conv2d.gemm_1x1, Conv2d.hip_wgrad_kxk)
     Conv2d.cpp_nodes, Conv2d.gemm_1x1, Conv2d.hip_wgrad_kxk = False, False, False
+    def fwd(enc, img):
+        if not densecl:
+            return enc(img).float().mean()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            feat = enc.backbone(img)[3]
+        out = enc.neck(feat.float())                      # the DenseCL neck runs in fp32, as in the step
+        return out["x_global_proj"].mean() + out["x_local_proj"].mean()
     try:
         with FlopCounterMode(display=False) as fc:
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                y = model.encoder_q(batch["img_a"])
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=not densecl):
+                y = fwd(model.encoder_q, batch["img_a"])
                 with torch.no_grad():
-                    model.encoder_k(batch["img_b"])
-            y.float().mean().backward()
+                    fwd(model.encoder_k, batch["img_b"])
+            y.backward()
     finally:
         Conv2d.cpp_nodes, Conv2d.gemm_1x1, Conv2d.hip_wgrad_kxk = saved
     model.encoder_q.zero_grad(set_to_none=True)
@@ -198,14 +241,15 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     rehearse = args.rehearse_collectives and world == 1
+    from cp2_amd import dist as cdist
     if world > 1:
-        dist.init_process_group(args.backend, rank=rank, world_size=world)
-    elif rehearse:
+        # bounded timeout (torch's nccl default, 10 min, is the driver's whole bench limit) + the hang watchdog that names the
+        # exchange step (C1 / C3 / C4 / gradient bucket i) a stuck rank was waiting for, exit code cdist.HANG_EXIT_CODE
+        cdist.init_process_group(args.backend, rank, world, timeout_s=args.timeout)
+    elif rehearse:              # a one-rank group: every exchange step of the N > 1 path is issued (dist.multi()), nothing moves
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(_free_port()))
-        dist.init_process_group(args.backend, rank=0, world_size=1)
-        from cp2_amd import dist as cdist
-        cdist.FORCE_COLLECTIVES = True
+        cdist.init_process_group(args.backend, 0, 1, timeout_s=args.timeout)
 
     from cp2_amd import builder, ops, synthetic
     from cp2_amd.encoder import FusedBatchNorm2d
@@ -226,9 +270,12 @@ def main():
     cfg = Config.fromfile(args.config)
     amp = torch.bfloat16 if args.amp == "bf16" else None
     import contextlib
+    ptype = PretrainType.DENSECL if args.densecl else PretrainType.CP2
+    # DENSECL: the flag overrides of reference main.py:148-153 / scripts/10-11-densecl.sh:48-50 (T = 0.2 twice, lambda = 0.5)
+    extra = dict(instance_logits_temp=0.2, dense_logits_temp=0.2, lmbd_cp2_dense_loss=0.5) if args.densecl else {}
     with contextlib.redirect_stdout(sys.stderr):       # the constructor prints what the reference prints; stdout = the JSON line only
-        model = builder.MODEL(cfg, rank=rank, K=args.queue, pretrain_from_scratch=True, pretrain_type=PretrainType.CP2,
-                              device=dev, amp_dtype=amp, channels_last=True).to(dev)
+        model = builder.MODEL(cfg, rank=rank, K=args.queue, pretrain_from_scratch=True, pretrain_type=ptype,
+                              device=dev, amp_dtype=amp, channels_last=True, **extra).to(dev)
     model.encoder_q.to(memory_format=torch.channels_last)
     model.encoder_k.to(memory_format=torch.channels_last)
     model.train()
@@ -248,7 +295,7 @@ def main():
                          model=model if args.flat_sgd == "on" else None)
     b, hw = args.batch_per_gpu, args.img
     batches = [synthetic.make_batch(b, hw, hw, dev, seed=rank * 9973 + i) for i in range(4)]
-    flops_img = count_flops_per_image(torch, model, batches[0])
+    flops_img = count_flops_per_image(torch, model, batches[0], args.densecl)
     runner = TrainStep(wrapped, opt)
     if os.environ.get("CP2_BENCH_QUART", "1") != "1":
         model.log_quartiles = False
@@ -275,7 +322,7 @@ def main():
             model._momentum_update_key_encoder()
         return runner(batches[i % len(batches)])
 
-    host_issue = [None]
+    host_issue, local_dt = [None], [None]
 
     def timed_region(n_steps, timed_kernels):
         if world > 1:
@@ -284,6 +331,7 @@ def main():
         t0 = time.perf_counter()
         last = None
         for i in range(n_steps):
+            cdist.progress(i)
             last = one_step(i, timed_kernels)
         host_issue[0] = (time.perf_counter() - t0) / n_steps * 1e3      # host time to ENQUEUE a step (no device wait inside)
         torch.cuda.synchronize()
@@ -291,6 +339,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        local_dt[0] = dt
         if world > 1:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -298,12 +347,38 @@ def main():
         return dt, last
 
     for i in range(args.warmup):
+        cdist.progress(i)
         one_step(i, False)
     torch.cuda.synchronize()
+    # --overlap auto with peers: north_star asks for the key branch's exchange steps on a side HIP stream; with ONE rank the
+    # fork / join measured slower than the ~0.14 ms it hides -- but a one-rank rehearsal moves no bytes.
+    # So with real peers both forms are timed here, after the warm-up, and the faster one (MAX over the ranks) is used.
+    calib = None
+    if args.overlap == "auto" and world > 1 and not args.densecl:
+        k = max(5, args.calib_steps)
+        calib = {}
+        for name, mode in (("off", None), ("gather", "gather")):
+            model.overlap_key_branch = mode
+            for i in range(2):                               # the side stream's first use allocates; not timed
+                one_step(i, False)
+            dt_c, _ = timed_region(k, False)
+            calib[name] = round(dt_c / k * 1e3, 4)
+        choice = min(calib, key=calib.get)                   # dt is already the MAX over the ranks: every rank picks the same
+        model.overlap_key_branch = {"off": None, "gather": "gather"}[choice]
+        calib = {"steps_each": k, "ms_per_step": calib, "chosen": choice}
     ops.PROFILE = {}               # every profiled launch of the timed steps carries its own start/stop hipEvents
     model.comm_events = {} if (world > 1 or rehearse) else None
     dt, loss = timed_region(args.steps, True)
     host_issue_ms = host_issue[0]
+    per_rank = None
+    if world > 1:              # every rank's own step time and host issue time: a straggling or host-bound rank is visible
+        mine = torch.tensor([local_dt[0] / args.steps * 1e3, host_issue_ms], device=dev, dtype=torch.float64)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        ms_r, host_r = [float(t[0]) for t in allr], [float(t[1]) for t in allr]
+        per_rank = {"ms_per_step": {"min": round(min(ms_r), 3), "max": round(max(ms_r), 3), "by_rank": [round(v, 3) for v in ms_r]},
+                    "host_issue_ms_per_step": {"min": round(min(host_r), 3), "max": round(max(host_r), 3),
+                                               "by_rank": [round(v, 3) for v in host_r]}}
     loss_val = float(loss)
     assert loss_val == loss_val, "loss is NaN"
     prof, ops.PROFILE = ops.PROFILE or {}, None
@@ -328,7 +403,8 @@ def main():
             "backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(), "one_device_rehearsal": bool(args.one_device),
             "single_rank_rehearsal": bool(rehearse),
             "launcher": os.environ.get("CP2_BENCH_LAUNCHER", "external"), "shuffle_exchange": args.shuffle_exchange,
-            "overlap_key_branch": args.overlap, "grad_sync": args.grad_sync,
+            "overlap_key_branch": args.overlap, "overlap_used": {None: "off", False: "off", "gather": "gather", True: "on"}[model.overlap_key_branch],
+            "overlap_calibration": calib, "per_rank": per_rank, "timeout_s": args.timeout, "grad_sync": args.grad_sync,
             "ddp_bucket_mb": args.bucket_mb or builder.DDP_BUCKET_MB,
             "grad_buckets": len(wrapped.reducer.buckets) if args.grad_sync == "flat" else None,
             "ms_per_step": {   # stream time between the events around each exchange step (it includes waiting for peers)
@@ -377,44 +453,107 @@ def main():
                               "algorithmic: read p, g, momentum; write p, momentum in fp32; fused: + the bf16 image of the new query weights")
 
     # per-kernel figures of the other hand-written kernels of the step, each from its own launches' events
-    C, K, P = 128, args.queue, (hw // model.output_stride) ** 2
+    C, K = 128, args.queue
+    P = (hw // (model.backbone_output_stride if args.densecl else model.output_stride)) ** 2
     kernels = []
 
-    def add(name, kernel, bound, work, unit, peak, note):
+    def entry(name, kernel, bound, work, unit, peak, note, **more):
+        """`work` = algorithmic bytes / flops of ONE launch; several launches per step (the chunked statistics walk) are
+        averaged, so achieved = work / mean launch duration either way."""
         ms = avg_ms(name)
-        if ms:
-            ach = work / (ms * 1e-3) / (1e9 if unit == "GB/s" else 1e12)
-            kernels.append({"kernel": kernel, "bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": unit,
-                            "frac": round(ach / peak, 4), "avg_launch_us": round(ms * 1e3, 2), "work_per_launch": work, "note": note})
+        if not ms:
+            return None
+        ach = work / (ms * 1e-3) / (1e9 if unit == "GB/s" else 1e12)
+        e = {"kernel": kernel, "bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
+             "traffic": None, "avg_launch_us": round(ms * 1e3, 2), "launches_per_step": round(len(prof.get(name) or []) / args.steps, 2),
+             "work_per_launch": work, "note": note}
+        e.update(more)
+        return e
+
+    def add(*a, **kw):
+        e = entry(*a, **kw)
+        if e is not None:
+            kernels.append(e)
+        return e
     px_bytes = 4 * 3 * 4 + 2 * 3 * (2 if amp is not None else 4)      # per pixel: img_a, bg0, img_b, bg1 read in fp32; two views written
     add("compose_pair", "compose_pair_kernel (copy-paste composition of both views, builder.py:1146-1159, key rows in shuffle order)", "hbm",
         b * hw * hw * px_bytes, "GB/s", HBM_PEAK_GBS, "algorithmic bytes = 4 fp32 image reads + 2 composed views written (bf16 under autocast); "
         "PMC traffic 1.002 x (profiles/compose_traffic.json)")
-    add("rowkey_fwd", "rowkey_small_kernel (instance InfoNCE: q_pos x queue, builder.py:1395-1428)", "hbm", 4 * C * K, "GB/s",
-        HBM_PEAK_GBS, "algorithmic bytes = the fp32 queue read once (4*C*K); with quartile logging on the launch also writes the b x K logits")
-    add("dense_fwd", "dense_fwd_kernel (P x P logits + column soft-max statistics, builder.py:1289-1292,1431-1437)", "mfma", 2.0 * b * P * P * C,
-        "TFLOP/s", F32_MFMA_PEAK_TFLOPS, "f32-input MFMA; at P=196 the launch is latency-bound (64 (sample, tile) items)")
-    add("dense_bwd", "dense_bwd_kernel (recomputed logits + gradient product)", "mfma", 4.0 * b * P * P * C, "TFLOP/s", F32_MFMA_PEAK_TFLOPS,
-        "f32-input MFMA, two products per pair")
-    add("quantiles", "quantiles kernels (3 x 3 logging quartiles of the step)", "hbm", 4 * (b * K + 2 * b * P * P), "GB/s",
-        HBM_PEAK_GBS, "radix select, three passes over the rows: latency / LDS-atomic bound, not a streaming kernel")
+    add("rowkey_fwd", "rowkey_small_kernel (instance InfoNCE: q_pos x queue, builder.py:1395-1428; DenseCL: the global loss, :762-772)", "hbm",
+        4 * C * K, "GB/s", HBM_PEAK_GBS,
+        "algorithmic bytes = the fp32 queue read once (4*C*K); with quartile logging on the launch also writes the b x K logits")
+    dense_fwd = add("dense_fwd", "dense_fwd_kernel (P x P logits + column soft-max statistics, builder.py:1289-1292,1431-1437)", "mfma",
+                    2.0 * b * P * P * C, "TFLOP/s", F32_MFMA_PEAK_TFLOPS,
+                    "f32-input MFMA; at P=196 the launch is latency-bound (64 (sample, tile) items)")
+    dense_bwd = add("dense_bwd", "dense_bwd_kernel (recomputed P x P logits + gradient product, builder.py:1289-1292,1431-1437 backward)", "mfma",
+                    4.0 * b * P * P * C, "TFLOP/s", F32_MFMA_PEAK_TFLOPS, "f32-input MFMA (exact fp32 fma chains), two products per pixel pair")
+    # DenseCL: the rows-vs-queue kernel (T19).  One launch covers R_l rows: all b*P of them, or -- on rank 0 with the score
+    # statistics on -- one group of whole samples of the chunked walk (builder._queue_infonce_chunked)
+    rows_evs = prof.get("rowkey_fwd_rows") or []
+    rowkey_rows = None
+    if rows_evs:
+        R_l = b * P / (len(rows_evs) / args.steps)
+        useful = 4.0 * R_l * C * K                       # logits (2 R C K) + the gradient product sum_j p_j k_j (2 R C K)
+        if b * P >= 1024:           # what precision "auto" selects for the DenseCL row counts (ops.rowkey_infonce)
+            rowkey_rows = add("rowkey_fwd_rows", "rowkey_bf16x3_dma_kernel (DenseCL per-pixel rows x queue2, forward + fused gradient product, "
+                              "builder.py:866-873,906-908,150-176)", "mfma", useful, "TFLOP/s", BF16_DENSE_PEAK_TFLOPS,
+                              "achieved = USEFUL flop rate (2 products of 2*R*C*K: logits and gradient); split-bf16 (hi*hi + hi*lo + lo*hi) issues "
+                              "three bf16 MFMAs per product for logits within 3e-5 of fp32: the matrix pipe runs at achieved_issued",
+                              rows_per_launch=int(R_l))
+            if rowkey_rows is not None:
+                rowkey_rows["achieved_issued"] = round(3 * rowkey_rows["achieved"], 1)
+                rowkey_rows["frac_issued"] = round(3 * rowkey_rows["achieved"] / BF16_DENSE_PEAK_TFLOPS, 4)
+        else:
+            rowkey_rows = add("rowkey_fwd_rows", "rowkey_fwd_kernel (rows x queue in exact fp32, forward + fused gradient product, "
+                              "builder.py:866-873,906-908,150-176)", "mfma", useful, "TFLOP/s", F32_MFMA_PEAK_TFLOPS,
+                              "f32-input MFMA (fewer than 1024 rows: the exact-fp32 kernel)", rows_per_launch=int(R_l))
+    CE = getattr(model.encoder_q.backbone, "feat_dim", 2048)
+    add("densecl_match", "densecl_match_kernel (DenseCL positive selection: backbone-similarity arg-max + local positives, "
+        "builder.py:818-864)", "mfma", 2.0 * b * P * P * CE, "TFLOP/s", BF16_DENSE_PEAK_TFLOPS,
+        "bf16 MFMA on the backbone features as the encoder returns them (exact products, fp32 accumulation); at P=196 the launch is "
+        "bound by streaming the two 25.7 MB feature maps and by its 224 work items, not by the matrix pipe")
+    add("quantiles", "quantiles kernels (the logging quartiles of the step)", "hbm",
+        4 * ((b * K + 2 * b * P * P) if not args.densecl else (b * P * K + b * K) / max(1.0, len(prof.get("quantiles") or [1]) / args.steps)),
+        "GB/s", HBM_PEAK_GBS, "radix select over rows kept in registers: latency / LDS-atomic bound, not a streaming kernel")
     if sgd_entry is not None:
         kernels.insert(0, ema_entry)
+    # the line's `roofline` = the dominant hand-written kernel of THIS workload: cfg2 the optimizer update (HBM), cfg4 the
+    # dense backward (f32 MFMA), cfg5 the rows-vs-queue kernel (bf16 MFMA)
+    roofline = sgd_entry if sgd_entry is not None else ema_entry
+    if args.workload == "cfg4" and dense_bwd is not None:
+        roofline = dense_bwd
+        kernels = [k for k in kernels if k is not dense_bwd] + ([sgd_entry] if sgd_entry is not None else [])
+    elif args.workload == "cfg5" and rowkey_rows is not None:
+        roofline = rowkey_rows
+        kernels = [k for k in kernels if k is not rowkey_rows] + ([sgd_entry] if sgd_entry is not None else [])
     imgs = b * world * args.steps
     value = imgs / dt
+    depth = cfg.model["backbone"]["depth"]
+    head = cfg.model["decode_head"]
+    head_name = {"FCNHead": "FCN", "ASPPHead": "ASPP"}.get(head["type"], head["type"]) + ("(contrast)" if head.get("contrast") else "")
+    label = WORKLOADS[args.workload]["label"] if args.as_baseline else "custom sizes (not a BASELINE configuration)"
+    common = (f"{b} img/GPU, encoders bf16 autocast channels-last, " if amp is not None else f"{b} img/GPU, encoders fp32 channels-last, ")
+    if args.densecl:
+        method = "DenseCL"
+        workload = (f"{label}: DenseCL (scripts/10-11-densecl.sh) ResNet-{depth} backbone OS{model.backbone_output_stride} + DenseCL neck, "
+                    f"{hw}x{hw} crops, {P} pixels per image against queue2, queues 2 x {args.queue}, {common}"
+                    f"neck fp32, loss kernels split-bf16 / fp32 (logits within 3e-5), SGD(0.9, wd 1e-4), random-init weights")
+    else:
+        method = "CP2"
+        workload = (f"{label}: ResNet-{depth} + {head_name} head OS{model.output_stride}, {hw}x{hw} copy-paste pairs, "
+                    f"queue={args.queue}, {common}loss kernels fp32 (f32 MFMA), "
+                    f"SGD(0.9, wd 1e-4), random-init weights")
     out = {
-        "metric": "pretrain images/sec (whole node), ResNet-50 CP2 224^2, queue=65536",
+        "metric": f"pretrain images/sec (whole node), ResNet-{depth} {method} {hw}^2, queue={args.queue}",
         "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "host_issue_ms_per_step": round(host_issue_ms, 3),
         "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16" if amp is not None else "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: ResNet-50 + FCN(contrast) head OS16, {hw}x{hw} copy-paste pairs, "
-                               f"queue={args.queue}, {b} img/GPU, encoders bf16 autocast channels-last, loss kernels fp32 (f32 MFMA), "
-                               f"SGD(0.9, wd 1e-4), random-init weights",
+        "config": {"workload": workload,
                    "global_batch": b * world, "parallelism": f"dp{world}", "hipgraph": "key encoder forward only",
                    "final_loss": round(loss_val, 4)},
-        # the dominant hand-written kernel of the step by time: the optimizer update (then the EMA, first entry of roofline_kernels)
-        "roofline": sgd_entry if sgd_entry is not None else ema_entry,
+        # the dominant hand-written kernel of the step by time (cfg2: the optimizer update, then the EMA, first entry of roofline_kernels)
+        "roofline": roofline,
         "roofline_kernels": kernels,
         "step_compute": {"flops_per_img": round(flops_img / 1e9, 2), "unit": "GFLOP (encoders fwd+bwd, flop counter)",
                          "achieved_tflops_per_gpu": round(flops_img * b / (dt / args.steps) / 1e12, 1),
@@ -425,11 +564,13 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.cpu_step import time_cpu_baseline
         ips, threads, secs = time_cpu_baseline(cfg, synthetic.make_batch, args.cpu_batch, hw, hw, args.queue,
-                                               steps=args.cpu_steps, warmup=args.cpu_warmup)
+                                               steps=args.cpu_steps, warmup=args.cpu_warmup, densecl=args.densecl,
+                                               output_stride=model.output_stride)
         out["cpu_baseline"] = {"value": round(ips, 3), "unit": "images/sec", "cores": physical_cores(), "threads": threads,
                                "kind": "port",
                                "sample": f"{args.cpu_steps} steps of {args.cpu_batch} images ({hw}x{hw}, queue {args.queue}, "
-                                         f"same model) after {args.cpu_warmup} warm-up steps, fp32, {secs:.1f} s",
+                                         f"same model{', DenseCL step with the rank-0 score statistics' if args.densecl else ''}) "
+                                         f"after {args.cpu_warmup} warm-up steps, fp32, {secs:.1f} s",
                                "split_ms_per_step": time_cpu_baseline.last_split_ms}
     if rank == 0:
         sys.stdout.flush()

@@ -67,7 +67,7 @@ SIGNATURES = {
     "cp2_bn_bwd": [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, _P],
     "cp2_masked_quantiles": [_P, c_int64, c_int64, c_int, c_int, _P, _P, c_int, c_int, _P, c_int, _P, _P, c_int64, _P],
     "cp2_quantiles_workspace_bytes": [c_int, _P, _P, c_int],
-    "cp2_masked_quantiles_multi": [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, c_int, _P, c_int64, _P],
+    "cp2_masked_quantiles_multi": [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int64, _P],
     "cp2_maxpool3s2_fwd": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "cp2_maxpool3s2_bwd": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "cp2_cutpaste": [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],

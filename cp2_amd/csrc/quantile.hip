@@ -18,6 +18,8 @@
 //   K3  quantile_hist_kernel<2>   chunk: last 10 bits of the elements with the selected 22-bit prefix -> hist2, and the
 //                                 smallest key above that prefix (the interpolation partner when a bin's maximum is hit)
 //   S3  quantile_select_kernel<2> row:   final key, partner, interpolation; the row's workspace is left zeroed
+// The positive and the negative dense scores are two classes of ONE logit map (an element belongs to exactly one): their
+// two jobs are served by one read of the map per level (round 4: 6 x 1.07 GB -> 3 x 1.07 GB per call at config 4).
 // Every level counts ALL matching elements, so the cost does not depend on the data: an earlier form of this path
 // compacted the first-level candidates and finished them in one workgroup per row -- 1.2 ms on Gaussian test data, but
 // the dense logits of a freshly initialised encoder are a handful of distinct fp32 values next to 1.0, every candidate
@@ -38,6 +40,8 @@ struct QuantArgs {
     int R;
     int chunks;                                            // ceil(N / QCHUNK)
     float* mean_out;                                       // NULL, or [R]: mean of the row as torch's x.mean(1) (NaN if the row holds one); want < 0, row kernel only
+    int pair;                                              // chunked form: 1 = this job (want 1) and the next one (want 0) read the same logits:
+                                                           // its chunk workgroups fill both jobs' histograms from ONE read; 2 = that next job
 };
 
 __device__ __forceinline__ unsigned f2key(float f) {
@@ -66,13 +70,10 @@ struct QuantJobs {
     unsigned* hist2;                       // [rows][QMAX][QB1]
     unsigned* above;                       // [rows][QMAX] max over ~key of the elements above the 22-bit prefix (0 = none)
     unsigned* sel;                         // [rows][QSEL]: n | per quantile: prefix so far, rank inside it
-                                           //   (cooperative form: [0] arrivals, [1] departures, [2] time-out flag)
-    double* sums;                          // [rows][QCOOP_CHUNKS] partial row sums (cooperative form, mean_out)
 };
 constexpr int QSEL = 1 + 2 * QMAX;
-constexpr int QCOOP_CHUNKS = 16;           // chunks per row of the one-launch cooperative form (QROW_MAX / QCHUNK)
-// per-row workspace words: hist0 | hist1 | hist2 | above | sel | sums (the cooperative form's per-chunk partial row sums, doubles)
-constexpr int64_t QROW_WORDS = QB0 + 2 * QMAX * QB1 + QMAX + QSEL + 2 * QCOOP_CHUNKS;
+// per-row workspace words: hist0 | hist1 | hist2 | above | sel
+constexpr int64_t QROW_WORDS = QB0 + 2 * QMAX * QB1 + QMAX + QSEL;
 
 template <int NT>
 __device__ __forceinline__ unsigned block_scan_incl(unsigned v, unsigned* wtot) {
@@ -89,59 +90,6 @@ __device__ __forceinline__ unsigned block_scan_incl(unsigned v, unsigned* wtot) 
     unsigned base = 0;
     for (int j = 0; j < w; ++j) base += wtot[j];
     return incl + base;
-}
-
-// Visit the kept elements i in [begin, end) of row r (begin % 4 == 0): f(key).  16-byte loads when the row is contiguous.
-template <int NT, typename F>
-__device__ __forceinline__ void for_each_kept(const QuantArgs& a, int r, int begin, int end, F&& f) {
-    const float* row = a.x + (int64_t)r * a.s_row;
-    const bool masked = a.want >= 0;
-    const float* ma = masked ? a.mask_a + (int64_t)r * a.P : nullptr;
-    const float* mb = masked ? a.mask_b + (int64_t)r * a.P : nullptr;
-    const bool wantpos = a.want != 0;
-    const int tid = threadIdx.x;
-    const bool vec = a.s_elem == 1 && ((reinterpret_cast<uintptr_t>(row) & 15u) == 0);
-    if (vec) {
-        for (int i0 = begin + tid * 4; i0 < end; i0 += NT * 4 * 2) {
-            float4 t4[2];
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {                  // two 16-byte loads in flight
-                const int i = i0 + g * NT * 4;
-                if (i + 3 < end) {
-                    t4[g] = *reinterpret_cast<const float4*>(row + i);
-                } else {
-                    t4[g].x = (i + 0 < end) ? row[i + 0] : NAN;
-                    t4[g].y = (i + 1 < end) ? row[i + 1] : NAN;
-                    t4[g].z = (i + 2 < end) ? row[i + 2] : NAN;
-                    t4[g].w = NAN;
-                }
-            }
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const int i = i0 + g * NT * 4;
-                if (i >= end) break;
-                const float vv[4] = {t4[g].x, t4[g].y, t4[g].z, t4[g].w};
-                int x_ = 0, y_ = 0;
-                float fa = 0.f;
-                if (masked) { x_ = i / a.P; y_ = i - x_ * a.P; fa = ma[x_]; }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float v = vv[u];
-                    bool keep = v == v;                    // nanquantile ignores NaN (also the padding above)
-                    if (masked && keep) keep = ((fa * mb[y_]) != 0.f) == wantpos;
-                    if (keep) f(f2key(v));
-                    if (masked && ++y_ >= a.P) { y_ = 0; ++x_; fa = (x_ < a.P) ? ma[x_] : 0.f; }
-                }
-            }
-        }
-    } else {
-        for (int i = begin + tid; i < end; i += NT) {
-            const float v = row[(int64_t)i * a.s_elem];
-            bool keep = v == v;
-            if (masked && keep) { const int x_ = i / a.P; keep = ((ma[x_] * mb[i - x_ * a.P]) != 0.f) == wantpos; }
-            if (keep) f(f2key(v));
-        }
-    }
 }
 
 // One chunk (QCHUNK elements = 8 float4 per thread of a 256-thread workgroup), split into "issue every load" and
@@ -173,13 +121,24 @@ __device__ __forceinline__ void chunk_load(const QuantArgs& a, int r, int begin,
     }
 }
 
+// Visit the elements of one chunk: f(key, cls) for every non-NaN element, cls = 1 for a positive pair
+// (mask_a[x] * mask_b[y] != 0), 0 for a negative pair or an unmasked job.  The caller filters by class.
 template <int NT, typename F>
 __device__ __forceinline__ void chunk_visit(const QuantArgs& a, int r, int begin, int end, const ChunkData<NT>& d, F&& f) {
-    if (!d.vec) { for_each_kept<NT>(a, r, begin, end, f); return; }
     const bool masked = a.want >= 0;
     const float* ma = masked ? a.mask_a + (int64_t)r * a.P : nullptr;
     const float* mb = masked ? a.mask_b + (int64_t)r * a.P : nullptr;
-    const bool wantpos = a.want != 0;
+    if (!d.vec) {                                          // strided or unaligned rows: element by element
+        const float* row = a.x + (int64_t)r * a.s_row;
+        for (int i = begin + (int)threadIdx.x; i < end; i += NT) {
+            const float v = row[(int64_t)i * a.s_elem];
+            if (v != v) continue;
+            int cls = 0;
+            if (masked) { const int x_ = i / a.P; cls = ((ma[x_] * mb[i - x_ * a.P]) != 0.f) ? 1 : 0; }
+            f(f2key(v), cls);
+        }
+        return;
+    }
     int x0 = 0, rem0 = 0;
     float invP = 0.f;
     bool mvec = false;
@@ -194,7 +153,7 @@ __device__ __forceinline__ void chunk_visit(const QuantArgs& a, int r, int begin
         const float vv[4] = {d.v[g].x, d.v[g].y, d.v[g].z, d.v[g].w};
         if (!masked) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) if (vv[u] == vv[u]) f(f2key(vv[u]));
+            for (int u = 0; u < 4; ++u) if (vv[u] == vv[u]) f(f2key(vv[u]), 0);
             continue;
         }
         // (x, y) of element i: rem0 + loc < P + QCHUNK, exact through a float quotient and one correction
@@ -209,16 +168,14 @@ __device__ __forceinline__ void chunk_visit(const QuantArgs& a, int r, int begin
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const float v = vv[u];
-                if (v == v && (((fa * mm[u]) != 0.f) == wantpos)) f(f2key(v));
+                if (v == v) f(f2key(v), ((fa * mm[u]) != 0.f) ? 1 : 0);
             }
         } else {
             float fa = x_ < a.P ? ma[x_] : 0.f;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const float v = vv[u];
-                bool keep = v == v;
-                if (keep) keep = ((fa * mb[y_]) != 0.f) == wantpos;
-                if (keep) f(f2key(v));
+                if (v == v) f(f2key(v), ((fa * mb[y_]) != 0.f) ? 1 : 0);
                 if (++y_ >= a.P) { y_ = 0; ++x_; fa = (x_ < a.P) ? ma[x_] : 0.f; }
             }
         }
@@ -249,58 +206,106 @@ __device__ __forceinline__ void locate(const unsigned (&hv)[BPT], unsigned excl,
 }
 
 // ---- chunk-parallel histogram of level LEVEL (0: top 12 bits of every kept element; 1: next 10 bits of the elements in
-// the selected first-level bin; 2: last 10 bits of the elements with the selected 22-bit prefix + smallest key above it)
+// the selected first-level bin; 2: last 10 bits of the elements with the selected 22-bit prefix + smallest key above it).
+// A chunk of a PAIRED job (QuantArgs::pair == 1: the positive and the negative class of one logit map) is read once and
+// every element goes to the histograms of its own class (side 0 = this job's row, side 1 = the next job's row).
+// Quantiles whose prefix so far is equal share one LDS histogram (on the narrow-band rows of a young encoder all three
+// quartiles sit in one bin: one LDS add per element instead of three); the flush adds it to each of their global ones.
 template <int LEVEL>
 __global__ __launch_bounds__(QT1) void quantile_hist_kernel(QuantJobs jobs) {
     constexpr int NB = LEVEL == 0 ? QB0 : QMAX * QB1;
-    __shared__ unsigned h[NB];
-    __shared__ unsigned sh_min[QMAX];
+    __shared__ unsigned h[2 * NB];
+    __shared__ unsigned sh_min[2 * QMAX];
     const int jsel = job_of(jobs.first_chunk, (int)blockIdx.x);
     const QuantArgs& a = jobs.job[jsel];
     const int c = (int)blockIdx.x - jobs.first_chunk[jsel], r = c / a.chunks, s = c - r * a.chunks;
     const int tid = threadIdx.x, NQ = a.NQ;
-    const int64_t rt = jobs.first_row[jsel] + r;
-    const unsigned* sel = jobs.sel + rt * QSEL;
-    if (LEVEL > 0 && sel[0] == 0u) return;                 // nothing kept in this row (workgroup-uniform)
+    const bool pair = a.pair == 1;
+    const int nside = pair ? 2 : 1;
+    const int64_t rt[2] = {jobs.first_row[jsel] + r, pair ? jobs.first_row[jsel + 1] + r : 0};
+    const unsigned* sel[2] = {jobs.sel + rt[0] * QSEL, jobs.sel + rt[1] * QSEL};
+    bool live[2] = {true, pair};
+    if (LEVEL > 0) {
+        live[0] = sel[0][0] != 0u;
+        live[1] = pair && sel[1][0] != 0u;
+        if (!live[0] && !live[1]) return;                  // nothing kept in this row (workgroup-uniform)
+    }
     const int begin = s * QCHUNK, end = min(a.N, begin + QCHUNK);
     ChunkData<QT1> d;
     chunk_load<QT1>(a, r, begin, end, d);                  // every load of the workgroup in flight
-    unsigned pre[QMAX], mn[QMAX];
+    // class -> side: unpaired masked job: only class `want` counts (side 0); paired: positives side 0, negatives side 1
+    const int side_of_cls[2] = {pair ? 1 : ((a.want < 0 || a.want == 0) ? 0 : -1), pair ? 0 : ((a.want < 0 || a.want == 1) ? 0 : -1)};
+    unsigned pre[2][QMAX], eff[2][QMAX], mn[2][QMAX];
+    int slot[2][QMAX];
 #pragma unroll
-    for (int j = 0; j < QMAX; ++j) { pre[j] = (LEVEL > 0 && j < NQ) ? sel[1 + 2 * j] : QNONE; mn[j] = QNONE; }
-    for (int i = tid; i < NB; i += QT1) h[i] = 0;
-    if (LEVEL == 2 && tid < QMAX) sh_min[tid] = QNONE;
+    for (int sd = 0; sd < 2; ++sd) {
+#pragma unroll
+        for (int j = 0; j < QMAX; ++j) {
+            pre[sd][j] = (LEVEL > 0 && j < NQ && live[sd]) ? sel[sd][1 + 2 * j] : QNONE;
+            slot[sd][j] = j;
+#pragma unroll
+            for (int i = j - 1; i >= 0; --i)
+                if (pre[sd][i] == pre[sd][j]) slot[sd][j] = i;
+            eff[sd][j] = slot[sd][j] == j ? pre[sd][j] : QNONE;      // a duplicate prefix counts in the first one's histogram
+            mn[sd][j] = QNONE;
+        }
+    }
+    for (int i = tid; i < nside * NB; i += QT1) h[i] = 0;
+    if (LEVEL == 2 && tid < 2 * QMAX) sh_min[tid] = QNONE;
     __syncthreads();
-    chunk_visit<QT1>(a, r, begin, end, d, [&](unsigned k) {
+    chunk_visit<QT1>(a, r, begin, end, d, [&](unsigned k, int cls) {
+        const int sd = side_of_cls[cls];
+        if (sd < 0) return;
         if (LEVEL == 0) {
-            atomicAdd(&h[k >> 20], 1u);
+            atomicAdd(&h[sd * NB + (k >> 20)], 1u);
         } else {
             const unsigned top = LEVEL == 1 ? (k >> 20) : (k >> 10);
             const unsigned bin = LEVEL == 1 ? ((k >> 10) & (QB1 - 1)) : (k & (QB1 - 1));
 #pragma unroll
             for (int j = 0; j < QMAX; ++j) {
-                if (top == pre[j]) atomicAdd(&h[j * QB1 + bin], 1u);
-                else if (LEVEL == 2 && j < NQ && top > pre[j]) mn[j] = min(mn[j], k);
+                const unsigned e = sd ? eff[1][j] : eff[0][j];
+                if (top == e) atomicAdd(&h[sd * NB + j * QB1 + bin], 1u);
+                if (LEVEL == 2) {
+                    const unsigned p = sd ? pre[1][j] : pre[0][j];
+                    if (p != QNONE && top > p) { if (sd) mn[1][j] = min(mn[1][j], k); else mn[0][j] = min(mn[0][j], k); }
+                }
             }
         }
     });
     if (LEVEL == 2) {
 #pragma unroll
-        for (int j = 0; j < QMAX; ++j) {
-            unsigned m = mn[j];
+        for (int sd = 0; sd < 2; ++sd) {
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, off, 64));
-            if ((tid & 63) == 0 && m != QNONE) atomicMin(&sh_min[j], m);
+            for (int j = 0; j < QMAX; ++j) {
+                unsigned m = mn[sd][j];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, off, 64));
+                if ((tid & 63) == 0 && m != QNONE) atomicMin(&sh_min[sd * QMAX + j], m);
+            }
         }
     }
     __syncthreads();
-    unsigned* g = LEVEL == 0 ? jobs.hist0 + rt * QB0 : (LEVEL == 1 ? jobs.hist1 : jobs.hist2) + rt * QMAX * QB1;
-    const int nb = LEVEL == 0 ? QB0 : NQ * QB1;
-    for (int i = tid; i < nb; i += QT1) {
-        const unsigned v = h[i];
-        if (v) atomicAdd(&g[i], v);
+    for (int sd = 0; sd < nside; ++sd) {
+        if (!live[sd]) continue;
+        if (LEVEL == 0) {
+            unsigned* g = jobs.hist0 + rt[sd] * QB0;
+            for (int i = tid; i < QB0; i += QT1) {
+                const unsigned v = h[sd * NB + i];
+                if (v) atomicAdd(&g[i], v);
+            }
+        } else {
+            unsigned* g = (LEVEL == 1 ? jobs.hist1 : jobs.hist2) + rt[sd] * QMAX * QB1;
+            for (int j = 0; j < NQ; ++j) {
+                const int sj = sd ? slot[1][j] : slot[0][j];
+                for (int i = tid; i < QB1; i += QT1) {
+                    const unsigned v = h[sd * NB + sj * QB1 + i];
+                    if (v) atomicAdd(&g[j * QB1 + i], v);
+                }
+            }
+            if (LEVEL == 2 && tid < NQ && sh_min[sd * QMAX + tid] != QNONE)
+                atomicMax(&jobs.above[rt[sd] * QMAX + tid], ~sh_min[sd * QMAX + tid]);
+        }
     }
-    if (LEVEL == 2 && tid < NQ && sh_min[tid] != QNONE) atomicMax(&jobs.above[rt * QMAX + tid], ~sh_min[tid]);
 }
 
 // ---- per-row select after level LEVEL: one workgroup per row
@@ -923,216 +928,6 @@ __global__ __launch_bounds__(QT3) void quantiles_row_kernel(QuantJobs jobs) {
     }
 }
 
-// ---- rows of at most QROW_MAX elements, a few hundred chunks in total (the training step: 576): ONE launch, one
-// 256-thread workgroup per 8192-element chunk.  The chunk is loaded once and stays in registers through the three levels;
-// after each level the chunks of a row meet at a row-local barrier (an arrival counter in the workspace: every chunk of
-// the call is resident at once -- the host only takes this path below QCOOP_MAX_WGS workgroups, a fraction of the 256 CUs'
-// slots -- so the spin ends; it is bounded anyway and raises a flag in the workspace instead of hanging).  Every chunk
-// re-derives the row's selection from the global histograms itself, so a level costs one barrier, not two; the row's
-// first chunk writes the result and leaves the workspace zero for the next call.
-// Round 2 had one 1024-thread workgroup per row walk its row three times (66 us: ~30 VALU instructions per element on
-// the ONE CU a row had; 96 of 256 CUs busy); here 576 workgroups share the same work.
-constexpr int QCOOP_MAX_WGS = 768;      // 256 CUs x 3 resident workgroups (launch bounds below): every chunk of the call is on the chip at once
-
-__device__ __forceinline__ unsigned ld_agent(const unsigned* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// All chunks of the row have arrived `target` times in total.  Returns false on time-out (flag raised).
-// No agent-scope fence: everything the chunks exchange is written by agent-scope atomics and read by agent-scope atomic
-// loads (performed at the device's coherence point), and __syncthreads() -- a workgroup-scope release, i.e. "every memory
-// operation of the workgroup has completed" -- stands between a chunk's last histogram add and its arrival.  A
-// __threadfence() here is an L2 write-back + invalidate per workgroup and barrier: measured 144 us for the launch
-// against 63 us for the one-workgroup-per-row kernel it replaces.
-__device__ __forceinline__ bool row_barrier(unsigned* sel, unsigned target) {
-    __shared__ int ok;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicAdd(&sel[0], 1u);
-        unsigned spins = 0;
-        bool good = true;
-        while (ld_agent(&sel[0]) < target) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 22)) { atomicExch(&sel[2], 1u); good = false; break; }
-        }
-        ok = good;
-    }
-    __syncthreads();
-    return ok != 0;
-}
-
-__global__ __launch_bounds__(QT1, 3) void quantiles_coop_kernel(QuantJobs jobs) {      // 3 workgroups per CU: 768 resident
-    constexpr int BPT0 = QB0 / QT1, BPT1 = QB1 / QT1;
-    __shared__ unsigned h[QMAX * QB1];                      // level 0 uses it as the QB0-bin histogram (QB0 == QMAX * QB1)
-    __shared__ unsigned wtot[QT1 / 64];
-    __shared__ unsigned sh_min[QMAX], sh_bin[QMAX], sh_kk[QMAX], sh_next[QMAX], sh_n;
-    __shared__ double sum_w[QT1 / 64];
-    static_assert(QB0 == QMAX * QB1, "one LDS histogram serves every level");
-    const int jsel = job_of(jobs.first_chunk, (int)blockIdx.x);
-    const QuantArgs& a = jobs.job[jsel];
-    const int c = (int)blockIdx.x - jobs.first_chunk[jsel], r = c / a.chunks, s = c - r * a.chunks;
-    const int tid = threadIdx.x, NQ = a.NQ, G = a.chunks;
-    const int64_t rt = jobs.first_row[jsel] + r;
-    unsigned* sel = jobs.sel + rt * QSEL;
-    unsigned* g0 = jobs.hist0 + rt * QB0;
-    unsigned* g1 = jobs.hist1 + rt * QMAX * QB1;
-    unsigned* g2 = jobs.hist2 + rt * QMAX * QB1;
-    const int begin = s * QCHUNK, end = min(a.N, begin + QCHUNK);
-    ChunkData<QT1> d;
-    chunk_load<QT1>(a, r, begin, end, d);                  // the only read of the data
-    // ---------------------------------------------------------------- level 0: top 12 bits of every kept element
-    for (int i = tid; i < QB0; i += QT1) h[i] = 0;
-    __syncthreads();
-    float lsum = 0.f;
-    chunk_visit<QT1>(a, r, begin, end, d, [&](unsigned k) { atomicAdd(&h[k >> 20], 1u); lsum += key2f(k); });
-    if (a.mean_out) {
-        double ds = (double)lsum;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) ds += __shfl_xor(ds, off, 64);
-        if ((tid & 63) == 0) sum_w[tid >> 6] = ds;
-    }
-    __syncthreads();
-    for (int i = tid; i < QB0; i += QT1) {
-        const unsigned v = h[i];
-        if (v) atomicAdd(&g0[i], v);
-    }
-    if (a.mean_out && tid == 0) {
-        double t = 0;
-        for (int i = 0; i < QT1 / 64; ++i) t += sum_w[i];
-        __hip_atomic_store(&jobs.sums[rt * QCOOP_CHUNKS + s], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (!row_barrier(sel, (unsigned)G)) return;
-    unsigned n;
-    {   // select 0, by every chunk for itself: rank -> (first-level bin, rank inside it)
-        unsigned hv[BPT0];
-#pragma unroll
-        for (int u = 0; u < BPT0; ++u) hv[u] = ld_agent(&g0[BPT0 * tid + u]);
-        unsigned tot = 0;
-#pragma unroll
-        for (int u = 0; u < BPT0; ++u) tot += hv[u];
-        const unsigned incl = block_scan_incl<QT1>(tot, wtot), excl = incl - tot;
-        if (tid == QT1 - 1) sh_n = incl;
-        __syncthreads();
-        n = sh_n;
-        if (n > 0)
-            for (int j = 0; j < NQ; ++j) locate<BPT0>(hv, excl, incl, (unsigned)floorf(a.q[j] * (float)(n - 1)), &sh_bin[j], &sh_kk[j]);
-        __syncthreads();
-    }
-    unsigned pre[QMAX], kk[QMAX];
-#pragma unroll
-    for (int j = 0; j < QMAX; ++j) { pre[j] = (n > 0 && j < NQ) ? sh_bin[j] : QNONE; kk[j] = (n > 0 && j < NQ) ? sh_kk[j] : 0u; }
-    // ---------------------------------------------------------------- levels 1 and 2: ten more bits each, per quantile
-    unsigned hv2[QMAX][BPT1];
-    for (int level = 1; level <= 2; ++level) {
-        unsigned* g = level == 1 ? g1 : g2;
-        __syncthreads();
-        for (int i = tid; i < QMAX * QB1; i += QT1) h[i] = 0;
-        if (tid < QMAX) sh_min[tid] = QNONE;
-        __syncthreads();
-        if (n > 0) {
-            unsigned mn[QMAX];
-#pragma unroll
-            for (int j = 0; j < QMAX; ++j) mn[j] = QNONE;
-            chunk_visit<QT1>(a, r, begin, end, d, [&](unsigned k) {
-                const unsigned top = level == 1 ? (k >> 20) : (k >> 10);
-                const unsigned bin = level == 1 ? ((k >> 10) & (QB1 - 1)) : (k & (QB1 - 1));
-#pragma unroll
-                for (int j = 0; j < QMAX; ++j) {
-                    if (top == pre[j]) atomicAdd(&h[j * QB1 + bin], 1u);
-                    else if (level == 2 && j < NQ && top > pre[j]) mn[j] = min(mn[j], k);
-                }
-            });
-            if (level == 2) {
-#pragma unroll
-                for (int j = 0; j < QMAX; ++j) {
-                    unsigned m = mn[j];
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, off, 64));
-                    if ((tid & 63) == 0 && m != QNONE) atomicMin(&sh_min[j], m);
-                }
-            }
-            __syncthreads();
-            for (int i = tid; i < NQ * QB1; i += QT1) {
-                const unsigned v = h[i];
-                if (v) atomicAdd(&g[i], v);
-            }
-            if (level == 2 && tid < NQ && sh_min[tid] != QNONE) atomicMax(&jobs.above[rt * QMAX + tid], ~sh_min[tid]);
-        }
-        if (!row_barrier(sel, (unsigned)((level + 1) * G))) return;
-        if (s == 0) {                                      // the previous level's histogram has been read by everyone
-            unsigned* z = level == 1 ? g0 : g1;
-            for (int i = tid; i < QB0; i += QT1) z[i] = 0u;
-        }
-        if (level == 2 && s != 0) break;                   // only the row's first chunk finishes the row
-        if (n == 0) continue;
-#pragma unroll
-        for (int j = 0; j < QMAX; ++j)
-#pragma unroll
-            for (int u = 0; u < BPT1; ++u) hv2[j][u] = j < NQ ? ld_agent(&g[j * QB1 + BPT1 * tid + u]) : 0u;
-        if (tid < QMAX) sh_next[tid] = QNONE;
-#pragma unroll
-        for (int j = 0; j < QMAX; ++j) {
-            if (j < NQ) {
-                unsigned tot = 0;
-#pragma unroll
-                for (int u = 0; u < BPT1; ++u) tot += hv2[j][u];
-                const unsigned incl = block_scan_incl<QT1>(tot, wtot);
-                locate<BPT1>(hv2[j], incl - tot, incl, kk[j], &sh_bin[j], &sh_kk[j]);
-            }
-        }
-        __syncthreads();
-        if (level == 1) {
-#pragma unroll
-            for (int j = 0; j < QMAX; ++j)
-                if (j < NQ) { pre[j] = (pre[j] << 10) | sh_bin[j]; kk[j] = sh_kk[j]; }
-        }
-    }
-    // ---------------------------------------------------------------- the row's first chunk: result, workspace back to zero
-    if (s == 0) {
-        if (n == 0) {
-            if (tid < NQ) a.out[(int64_t)tid * a.R + r] = NAN;
-        } else {
-            // the next non-empty third-level bin above the selected one (the partner when the selected key is not repeated)
-#pragma unroll
-            for (int j = 0; j < QMAX; ++j)
-#pragma unroll
-                for (int u = 0; u < BPT1; ++u)
-                    if (j < NQ && hv2[j][u] != 0 && (unsigned)(BPT1 * tid + u) > sh_bin[j]) atomicMin(&sh_next[j], (unsigned)(BPT1 * tid + u));
-            __syncthreads();
-            if (tid < NQ) {
-                const int j = tid;
-                const float rank = a.q[j] * (float)(n - 1);
-                const float lo_f = floorf(rank), w = rank - lo_f;
-                const unsigned key_lo = (pre[j] << 10) | sh_bin[j];
-                const float v_lo = key2f(key_lo);
-                float v_hi = v_lo;
-                if (w != 0.f) {
-                    const unsigned mult = ld_agent(&g2[j * QB1 + sh_bin[j]]);
-                    if (sh_kk[j] + 1 >= mult) {            // the element of rank lo + 1 is a larger key
-                        const unsigned ab = ld_agent(&jobs.above[rt * QMAX + j]);
-                        if (sh_next[j] != QNONE) v_hi = key2f((pre[j] << 10) | sh_next[j]);
-                        else if (ab != 0u) v_hi = key2f(~ab);
-                    }
-                }
-                const float dlt = v_hi - v_lo;               // at::lerp: w < 0.5 ? a + w*(b-a) : b - (b-a)*(1-w)
-                a.out[(int64_t)j * a.R + r] = (w < 0.5f) ? v_lo + w * dlt : v_hi - dlt * (1.f - w);
-            }
-        }
-        if (a.mean_out && tid == 0) {
-            double t = 0;
-            for (int i = 0; i < G; ++i) t += __hip_atomic_load(&jobs.sums[rt * QCOOP_CHUNKS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            a.mean_out[r] = (n == (unsigned)a.N) ? (float)(t / (double)a.N) : NAN;     // a NaN element makes torch's mean NaN
-        }
-        __syncthreads();
-        for (int i = tid; i < QMAX * QB1; i += QT1) g2[i] = 0u;
-        if (tid < QMAX) jobs.above[rt * QMAX + tid] = 0u;
-        if (tid < QCOOP_CHUNKS) jobs.sums[rt * QCOOP_CHUNKS + tid] = 0.0;
-    }
-    // the last chunk to leave re-arms the row's counters (nobody reads them any more)
-    __syncthreads();
-    if (tid == 0 && atomicAdd(&sel[1], 1u) == (unsigned)G - 1u) { atomicExch(&sel[0], 0u); atomicExch(&sel[1], 0u); }
-}
-
 static int quant_check(const QuantArgs& a) {
     if (!a.x || !a.q || !a.out) return CP2_ERR_NULL;
     if (a.R <= 0 || a.N <= 0 || a.NQ <= 0) return CP2_ERR_SHAPE;
@@ -1147,7 +942,7 @@ static int64_t quant_ws_words(int njobs, const int* R, const int* N, int NQ) {
     int64_t rows = 0;
     for (int j = 0; j < njobs; ++j)
         if (R[j] > 0 && N[j] > 0) rows += R[j];
-    return rows * QROW_WORDS + 2;                          // + alignment slack for the doubles behind an odd word count
+    return rows * QROW_WORDS;
 }
 
 CP2_API int64_t cp2_quantiles_workspace_bytes(int njobs, const int* R, const int* N, int NQ) {
@@ -1155,42 +950,9 @@ CP2_API int64_t cp2_quantiles_workspace_bytes(int njobs, const int* R, const int
     return 4 * quant_ws_words(njobs, R, N, NQ);
 }
 
-// form: 0 = automatic (a workgroup per row for rows up to QROW_MAX), 1 = the same, explicitly, 2 = cooperative chunks
-static int quant_launch(QuantJobs& jobs, int njobs, int form, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+static int quant_launch(QuantJobs& jobs, int njobs, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
     bool small = true;
     for (int j = 0; j < njobs; ++j) small = small && jobs.job[j].N <= QROW_MAX;
-    int64_t coop_wgs = 0;
-    for (int j = 0; j < njobs; ++j) coop_wgs += (int64_t)jobs.job[j].R * cp2_cdiv(jobs.job[j].N > 0 ? jobs.job[j].N : 1, QCHUNK);
-    if (form < 0 || form > 2) return CP2_ERR_SHAPE;
-    if (form != 0 && !small) return CP2_ERR_UNSUPPORTED;
-    if (form == 2 && (!workspace || coop_wgs > QCOOP_MAX_WGS)) return CP2_ERR_UNSUPPORTED;
-    if (form == 2) {                                       // one launch, one workgroup per chunk, row-local barriers
-        if (!cp2_aligned16(workspace)) return CP2_ERR_ALIGN;
-        int rows = 0, chunks = 0;
-        int Rs[QJOBS], Ns[QJOBS];
-        for (int j = 0; j < njobs; ++j) {
-            QuantArgs& a = jobs.job[j];
-            int rc = quant_check(a);
-            if (rc) return rc;
-            a.chunks = cp2_cdiv(a.N, QCHUNK);
-            jobs.first_row[j] = rows;
-            jobs.first_chunk[j] = chunks;
-            rows += a.R;
-            chunks += a.R * a.chunks;
-            Rs[j] = a.R; Ns[j] = a.N;
-        }
-        for (int j = njobs; j <= QJOBS; ++j) { jobs.first_row[j] = rows; jobs.first_chunk[j] = chunks; }
-        if (4 * quant_ws_words(njobs, Rs, Ns, jobs.job[0].NQ) > workspace_bytes) return CP2_ERR_SHAPE;
-        unsigned* w = static_cast<unsigned*>(workspace);
-        jobs.hist0 = w;
-        jobs.hist1 = jobs.hist0 + (int64_t)rows * QB0;
-        jobs.hist2 = jobs.hist1 + (int64_t)rows * QMAX * QB1;
-        jobs.above = jobs.hist2 + (int64_t)rows * QMAX * QB1;
-        jobs.sel = jobs.above + (int64_t)rows * QMAX;
-        jobs.sums = reinterpret_cast<double*>(jobs.sel + (int64_t)rows * QSEL + (((int64_t)rows * (QMAX + QSEL)) & 1));   // 8-byte aligned
-        CP2_LAUNCH_PROFILED(quantiles_coop_kernel, dim3(chunks), dim3(QT1), 0, stream, jobs);
-        return cp2_launch_status();
-    }
     if (small) {                                           // one launch, one workgroup per row, no workspace
         size_t lds = 0;
         int rows = 0;
@@ -1210,6 +972,16 @@ static int quant_launch(QuantJobs& jobs, int njobs, int form, void* workspace, i
     if (!cp2_aligned16(workspace)) return CP2_ERR_ALIGN;
     int rows = 0, chunks = 0;
     int Rs[QJOBS], Ns[QJOBS];
+    for (int j = 0; j < njobs; ++j) jobs.job[j].pair = 0;
+    for (int j = 0; j + 1 < njobs; ++j) {                  // (want 1, want 0) over the same logits and masks: one read per level
+        QuantArgs& p = jobs.job[j];
+        QuantArgs& n = jobs.job[j + 1];
+        if (p.pair == 0 && p.want == 1 && n.want == 0 && p.x == n.x && p.s_row == n.s_row && p.s_elem == n.s_elem && p.N == n.N &&
+            p.R == n.R && p.P == n.P && p.mask_a == n.mask_a && p.mask_b == n.mask_b && p.NQ == n.NQ) {
+            p.pair = 1;
+            n.pair = 2;
+        }
+    }
     for (int j = 0; j < njobs; ++j) {
         QuantArgs& a = jobs.job[j];
         int rc = quant_check(a);
@@ -1218,8 +990,10 @@ static int quant_launch(QuantJobs& jobs, int njobs, int form, void* workspace, i
         jobs.first_row[j] = rows;
         jobs.first_chunk[j] = chunks;
         rows += a.R;
-        if ((int64_t)chunks + (int64_t)a.R * a.chunks > 0x7fffffff) return CP2_ERR_UNSUPPORTED;
-        chunks += a.R * a.chunks;
+        if (a.pair != 2) {                                 // the second job of a pair has no chunk workgroups of its own
+            if ((int64_t)chunks + (int64_t)a.R * a.chunks > 0x7fffffff) return CP2_ERR_UNSUPPORTED;
+            chunks += a.R * a.chunks;
+        }
         Rs[j] = a.R; Ns[j] = a.N;
     }
     for (int j = njobs; j <= QJOBS; ++j) { jobs.first_row[j] = rows; jobs.first_chunk[j] = chunks; }
@@ -1248,19 +1022,19 @@ CP2_API int cp2_masked_quantiles(const float* x, int64_t stride_row, int64_t str
                                  const float* mask_a, const float* mask_b, int P, int want, const float* q, int NQ,
                                  float* out, void* workspace, int64_t workspace_bytes, void* stream) {
     QuantJobs jobs{};
-    jobs.job[0] = QuantArgs{x, stride_row, stride_elem, N, mask_a, mask_b, P, want, q, NQ, out, R, 0, nullptr};
-    return quant_launch(jobs, 1, 0, workspace, workspace_bytes, cp2_stream(stream));
+    jobs.job[0] = QuantArgs{x, stride_row, stride_elem, N, mask_a, mask_b, P, want, q, NQ, out, R, 0, nullptr, 0};
+    return quant_launch(jobs, 1, workspace, workspace_bytes, cp2_stream(stream));
 }
 
 CP2_API int cp2_masked_quantiles_multi(int njobs, const float* const* x, const int64_t* stride_row, const int64_t* stride_elem,
                                        const int* R, const int* N, const float* const* mask_a, const float* const* mask_b,
                                        const int* P, const int* want, const float* q, int NQ, float* const* out,
-                                       float* const* mean_out, int form, void* workspace, int64_t workspace_bytes, void* stream) {
+                                       float* const* mean_out, void* workspace, int64_t workspace_bytes, void* stream) {
     if (njobs <= 0 || njobs > QJOBS) return CP2_ERR_UNSUPPORTED;
     if (!x || !stride_row || !stride_elem || !R || !N || !mask_a || !mask_b || !P || !want || !out) return CP2_ERR_NULL;
     QuantJobs jobs{};
     for (int j = 0; j < njobs; ++j)
         jobs.job[j] = QuantArgs{x[j], stride_row[j], stride_elem[j], N[j], mask_a[j], mask_b[j], P[j], want[j], q, NQ, out[j], R[j], 0,
-                                mean_out ? mean_out[j] : nullptr};
-    return quant_launch(jobs, njobs, form, workspace, workspace_bytes, cp2_stream(stream));
+                                mean_out ? mean_out[j] : nullptr, 0};
+    return quant_launch(jobs, njobs, workspace, workspace_bytes, cp2_stream(stream));
 }

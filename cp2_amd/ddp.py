@@ -110,8 +110,27 @@ class GradReducer:
             self._ready(i)
         return hook
 
+    def reset(self) -> None:
+        """Forget a backward pass that did not reach its end (an exception inside backward() skips the engine's final
+        callbacks, so _finish never ran): without this the next pass would neither re-arm nor all-reduce, and the replicas
+        would drift apart silently.  FlatDDP.forward calls it, as DDP prepares its reducer at every forward."""
+        if self._armed:
+            for w in self._works:
+                try:
+                    w.wait()
+                except Exception:                    # noqa: BLE001 -- the pass is being abandoned anyway
+                    pass
+        self._armed = False
+        self._works, self._keep, self._next, self._left = [], [], 0, []
+
+    def table_hash(self) -> int:
+        """A hash of everything the ranks must agree on to issue the same collectives in the same order."""
+        import zlib
+        text = repr((self.buckets, self.ranges, self.expect, self.world)).encode()
+        return zlib.crc32(text) | (len(self.buckets) << 32)
+
     def _ready(self, i: int) -> None:
-        if not self.enabled or (self.world == 1 and not cdist.FORCE_COLLECTIVES):
+        if not self.enabled:
             return
         if not self._armed:
             self._armed = True
@@ -146,7 +165,9 @@ class GradReducer:
             ops.pack_grads(self._plan, self.flat, self._ptrs, lo, hi, self.scale)
         self._keep.append(grads)                          # alive until the pack launch is ordered before their reuse
         f_lo, f_hi = self.ranges[b]
-        self._works.append(dist.all_reduce(self.flat[f_lo:f_hi], op=dist.ReduceOp.SUM, async_op=True))
+        work = dist.all_reduce(self.flat[f_lo:f_hi], op=dist.ReduceOp.SUM, async_op=True)
+        self._works.append(cdist.COLLECTIVES.note(f"c5 gradient all-reduce, bucket {b} of {len(self.buckets)} "
+                                                  f"({(f_hi - f_lo) * 4 >> 20} MB)", work))
 
     def _finish(self) -> None:
         """End of the backward pass (autograd engine callback): wait for the all-reduces, hand out the averaged gradients."""
@@ -187,6 +208,10 @@ class FlatDDP(torch.nn.Module):
                                "runs on the GPU only")
         self.reducer = GradReducer(params, module._flat_offsets, module._flat_q.numel(),
                                    builder.DDP_BUCKET_MB if bucket_mb is None else bucket_mb)
+        # the bucket table is derived on every rank from its own parameter list: a rank that froze another set of
+        # parameters, or was built with another bucket size, would issue other all-reduces and the job would hang in the
+        # first backward pass -- fail here instead, with the ranks named
+        cdist.assert_same_on_all_ranks("FlatDDP bucket table", self.reducer.table_hash(), params[0].device)
 
     @torch.no_grad()
     def _broadcast_state(self) -> None:
@@ -204,6 +229,7 @@ class FlatDDP(torch.nn.Module):
             m._refresh_query_shadow()
 
     def forward(self, *args, **kwargs):
+        self.reducer.reset()
         return self.module(*args, **kwargs)
 
     @contextlib.contextmanager

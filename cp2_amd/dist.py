@@ -11,10 +11,18 @@ reference's order (tests/test_dist_gloo.py asserts equality with the all-gather 
 """
 from __future__ import annotations
 
+import collections
+import datetime
+import os
+import sys
+import threading
+import time
 from typing import Callable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
+
+DEFAULT_TIMEOUT_S = 120.0      # process-group timeout (torch's default for nccl is 10 min = the whole budget of a bench run)
 
 
 def is_dist() -> bool:
@@ -25,14 +33,121 @@ def world_size() -> int:
     return dist.get_world_size() if is_dist() else 1
 
 
-# Rehearsal switch (tests/test_gpu_nccl.py): run every collective and side-stream branch even with a single rank, so
-# the RCCL calls of the multi-GPU run are exercised on a one-GPU box.  Never set in production.
-FORCE_COLLECTIVES = False
-
-
 def multi() -> bool:
-    """True when the collectives of the hot path have to run (more than one rank, or the rehearsal switch)."""
-    return is_dist() and (world_size() > 1 or FORCE_COLLECTIVES)
+    """True when the collectives of the hot path run: whenever a process group exists.  One-rank groups included -- the
+    exchange steps then move nothing but are issued all the same, which is how bench.py --rehearse-collectives and
+    tests/test_gpu_nccl.py exercise the multi-GPU code path on a one-GPU box; cp2_amd.main creates a group only for
+    world_size > 1, so single-GPU training never pays for them."""
+    return is_dist()
+
+
+def init_process_group(backend: str, rank: int, world: int, init_method: Optional[str] = None,
+                       timeout_s: float = DEFAULT_TIMEOUT_S, watchdog: bool = True) -> None:
+    """The ONE place the package creates its process group (cp2_amd.main, bench.py, the multi-process tests):
+      * HSA_ENABLE_IPC_MODE_LEGACY=0 -- the dmabuf IPC path; with the legacy mode RCCL's peer-memory set-up fails on this
+        driver stack (hipIpcGetMemHandle: invalid argument), so it must be in the environment before the first HIP call of
+        a multi-process run, not only in bench.py;
+      * a bounded timeout (torch's nccl default is 10 minutes): a collective that never completes ends the process;
+      * the hang watchdog below, which says WHICH exchange step did not complete before that happens."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    kw = dict(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
+    if init_method:
+        kw["init_method"] = init_method
+    dist.init_process_group(**kw)
+    COLLECTIVES.clear()
+    if watchdog and world > 1:
+        start_watchdog(0.8 * timeout_s)
+
+
+# ---------------------------------------------------------------- which collective hangs?
+class _CollectiveLog:
+    """The last exchange steps this rank enqueued: (step, name, work handle or None).  With RCCL a hung collective shows
+    up minutes later as an abort from torch's watchdog thread that names an opcode and a sequence number; this log turns it
+    into "C3 key un-shuffle of step 17" (reference call sites: builder.py:612, :640, :572; main.py:456-461)."""
+
+    def __init__(self, keep: int = 64):
+        self.items = collections.deque(maxlen=keep)
+        self.step = 0
+
+    def clear(self):
+        self.items.clear()
+        self.step = 0
+
+    def note(self, name: str, work=None):
+        self.items.append((self.step, name, work))
+        return work
+
+    def first_incomplete(self):
+        for step, name, work in self.items:
+            try:
+                if work is not None and not work.is_completed():
+                    return step, name
+            except Exception:                       # noqa: BLE001 -- a backend without is_completed()
+                continue
+        return None
+
+    def describe(self) -> str:
+        inc = self.first_incomplete()
+        last = self.items[-1] if self.items else None
+        if inc is not None:
+            return f"first collective not completed: {inc[1]} (step {inc[0]})"
+        if last is not None:
+            return f"every tracked collective completed; last one enqueued: {last[1]} (step {last[0]})"
+        return "no collective was enqueued yet"
+
+
+COLLECTIVES = _CollectiveLog()
+_PROGRESS = [time.monotonic(), 0]
+_WATCHDOG: Optional[threading.Thread] = None
+HANG_EXIT_CODE = 3
+
+
+def progress(step: Optional[int] = None) -> None:
+    """Called by the training / bench loop once per step (host side): feeds the hang watchdog."""
+    _PROGRESS[0] = time.monotonic()
+    if step is not None:
+        _PROGRESS[1] = COLLECTIVES.step = step
+
+
+def start_watchdog(timeout_s: float, poll_s: float = 2.0, on_hang: Optional[Callable[[str], None]] = None) -> None:
+    """A daemon thread: no progress() for `timeout_s` seconds -> print which exchange step did not complete and end the
+    process with HANG_EXIT_CODE (the host thread may be blocked inside a HIP call by then; a blocked call releases the GIL).
+    Runs before the process group's own timeout so that the named message comes first."""
+    global _WATCHDOG
+    if _WATCHDOG is not None:
+        return
+    progress()
+
+    def run():
+        while True:
+            time.sleep(poll_s)
+            idle = time.monotonic() - _PROGRESS[0]
+            if idle > timeout_s:
+                msg = (f"cp2_amd: rank {rank()} of {world_size()} made no progress for {idle:.0f} s at step {_PROGRESS[1]}; "
+                       + COLLECTIVES.describe())
+                if on_hang is not None:
+                    on_hang(msg)
+                    return
+                print(msg, file=sys.stderr, flush=True)
+                os._exit(HANG_EXIT_CODE)
+
+    _WATCHDOG = threading.Thread(target=run, name="cp2-hang-watchdog", daemon=True)
+    _WATCHDOG.start()
+
+
+def assert_same_on_all_ranks(what: str, value: int, device=None) -> None:
+    """Every rank must hold the same `value` (a hash of something all ranks derive independently, e.g. FlatDDP's bucket
+    table): one small all-gather, RuntimeError naming the ranks that differ."""
+    if not multi():
+        return
+    on_dev = dist.get_backend() != "gloo" and device is not None
+    mine = torch.tensor([value & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64, device=device if on_dev else "cpu")
+    out = [torch.empty_like(mine) for _ in range(world_size())]
+    dist.all_gather(out, mine)
+    vals = [int(t) for t in out]
+    if len(set(vals)) != 1:
+        odd = [r for r, v in enumerate(vals) if v != vals[0]]
+        raise RuntimeError(f"{what} differs between ranks: ranks {odd} disagree with rank 0 ({vals})")
 
 
 def rank() -> int:
@@ -57,7 +172,9 @@ def concat_all_gather(tensor: torch.Tensor) -> torch.Tensor:
     if _gloo_on_gpu(tensor):
         dist.all_gather(list(out.chunk(world_size(), dim=0)), tensor)
     else:
-        dist.all_gather_into_tensor(out, tensor)
+        w = dist.all_gather_into_tensor(out, tensor, async_op=True)
+        COLLECTIVES.note(f"all_gather {tuple(tensor.shape)}", w)
+        w.wait()                    # orders the current stream behind the collective; the host does not block (RCCL)
     return out
 
 
@@ -130,6 +247,10 @@ class ShufflePlan:
         n = idx.numel()
         if n % w:
             raise ValueError(f"ShufflePlan: {n} rows do not split over {w} ranks")
+        if not torch.equal(torch.sort(idx).values, torch.arange(n)):
+            # the kernels clamp an out-of-range row to the identity for memory safety (cp2_compose_pair,
+            # cp2_feat_normalize_pool_pair): a bad table must be caught here, on the host, where it is built
+            raise ValueError("ShufflePlan: idx_shuffle is not a permutation of 0..n-1")
         b = n // w
         self.b, self.rank, self.world = b, r, w
         self.idx_shuffle = idx
@@ -176,7 +297,9 @@ def _all_to_all_rows(x: torch.Tensor, n_out: int, out_counts: List[int], in_coun
         dist.all_to_all_single(host, x.cpu(), out_counts, in_counts)
         out.copy_(host)
     else:
-        dist.all_to_all_single(out, x.contiguous(), out_counts, in_counts)
+        w = dist.all_to_all_single(out, x.contiguous(), out_counts, in_counts, async_op=True)
+        COLLECTIVES.note(f"all_to_all rows {tuple(x.shape)}", w)
+        w.wait()
     return out
 
 

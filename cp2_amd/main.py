@@ -28,6 +28,7 @@ import torch.multiprocessing as mp
 from torch.nn.parallel import DistributedDataParallel
 
 from . import builder, synthetic
+from . import dist as cdist
 from .ddp import FlatDDP
 from .config import Config
 from .engine import TrainStep
@@ -78,6 +79,9 @@ def get_args(argv=None):
     p.add_argument("--foreground_max", default=0.8, type=float)
     p.add_argument("--dist-url", default="tcp://127.0.0.1:10001", type=str)
     p.add_argument("--dist-backend", default="nccl", type=str)
+    p.add_argument("--dist_timeout", default=cdist.DEFAULT_TIMEOUT_S, type=float,
+                   help="seconds a collective may take before the process group aborts the run (additive flag; torch's nccl "
+                        "default is 600); the hang watchdog reports the exchange step that did not complete at 0.8 x this")
     p.add_argument("--world-size", default=1, type=int)
     p.add_argument("--epochs", default=200, type=int)
     p.add_argument("--max_steps", default=np.inf, type=float)
@@ -191,8 +195,10 @@ def main_worker(rank, args):
     np.random.seed(args.seed)
     torch.backends.cudnn.benchmark = True            # measured-fastest MIOpen solvers (1.4x on the encoder work)
     cfg = Config.fromfile(args.config)
-    if not dist.is_initialized():
-        dist.init_process_group(backend=args.dist_backend, init_method=args.dist_url, rank=rank, world_size=world)
+    if world > 1 and not dist.is_initialized():
+        # bounded timeout + hang watchdog + the RCCL environment, in one place (dist.init_process_group); a single-GPU run
+        # creates no process group at all, so none of the exchange steps is issued (dist.multi())
+        cdist.init_process_group(args.dist_backend, rank, world, init_method=args.dist_url, timeout_s=args.dist_timeout)
     model = build_model(args, cfg, rank, device).to(device)
     if not args.no_channels_last:
         model.encoder_q.to(memory_format=torch.channels_last)
@@ -255,6 +261,7 @@ def main_worker(rank, args):
                                              foreground_max=args.foreground_max)
             if args.same_foreground:
                 batch["img_b"], batch["pixel_ids_b"], batch["region_ids_b"] = batch["img_a"], batch["pixel_ids_a"], batch["region_ids_a"]
+            cdist.progress(step)
             loss = runner(batch)
             seen += per_gpu * world
             if i % args.print_freq == 0 and rank == 0:
@@ -271,7 +278,8 @@ def main_worker(rank, args):
                             filename=os.path.join(args.log_dir, args.run_id, f"{step}_{epoch}_checkpoint.ckpt"))
         if step > args.max_steps:
             break
-    dist.destroy_process_group()
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def main(argv=None):

@@ -815,10 +815,6 @@ def _quartile_tensor(device) -> torch.Tensor:
 _QUANT_WS = {}
 QUANTILES_ROW_MAX = 131072     # CP2_QUANTILES_ROW_MAX
 QUANTILES_CHUNK = 8192         # QCHUNK in csrc/quantile.hip
-QUANTILES_FORM = 0             # one-launch form for rows up to QUANTILES_ROW_MAX: 0 / 1 = one workgroup per row through the three
-                               # levels (the product path), 2 = one workgroup per chunk with row-local barriers (58.9 us against
-                               # 63.2 us; needs a workspace; not the default because of its spin-waits).  Identical results.
-QUANTILES_COOP_MAX_WGS = 768   # QCOOP_MAX_WGS: up to this many chunk workgroups the one-launch cooperative form is taken
 
 
 def _quant_workspace(dev, R, N, NQ):
@@ -870,22 +866,17 @@ def masked_quantiles_multi(jobs, q: Optional[torch.Tensor] = None):
             raise _lib.Cp2LibraryError("masked_quantiles: x must be a float32 GPU tensor")
     ma = [_opt(j.get("mask_a"), "mask_a", torch.float32) for j in jobs]
     mb = [_opt(j.get("mask_b"), "mask_b", torch.float32) for j in jobs]
-    # rows of at most QUANTILES_ROW_MAX elements: one launch -- one workgroup per 8192-element chunk with row-local
-    # barriers when the call is small enough for every chunk to be resident (the training step), else one workgroup per
-    # row and no workspace (DenseCL's thousands of rows); longer rows: the chunked six-launch path
+    # rows of at most QUANTILES_ROW_MAX elements: one launch, one workgroup per row, no workspace; longer rows: the chunked
+    # six-launch path with its zeroed workspace
     small = all(j["N"] <= QUANTILES_ROW_MAX for j in jobs)
-    form = QUANTILES_FORM if small else 0
-    if form == 2 and sum(j["R"] * -(-j["N"] // QUANTILES_CHUNK) for j in jobs) > QUANTILES_COOP_MAX_WGS:
-        form = 0                                          # too many chunks to be resident at once
-    ws = None if (small and form != 2) else \
-        _quant_workspace(dev, [j["R"] for j in jobs], [j["N"] for j in jobs], q.numel())
+    ws = None if small else _quant_workspace(dev, [j["R"] for j in jobs], [j["N"] for j in jobs], q.numel())
     _profile("quantiles")
     rc = lib.cp2_masked_quantiles_multi(
         n, P_(*[j["x"].data_ptr() for j in jobs]), I64(*[j["stride_row"] for j in jobs]), I64(*[j["stride_elem"] for j in jobs]),
         I32(*[j["R"] for j in jobs]), I32(*[j["N"] for j in jobs]), P_(*ma), P_(*mb),
         I32(*[(j["mask_a"].shape[1] if j.get("mask_a") is not None else 0) for j in jobs]),
         I32(*[j.get("want", -1) for j in jobs]), _dev(q, "q", torch.float32), q.numel(), P_(*[o.data_ptr() for o in outs]),
-        P_(*means) if any(m is not None for m in means) else None, form,
+        P_(*means) if any(m is not None for m in means) else None,
         None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel() * 4, _stream())
     if rc and ws is not None:
         ws.zero_()                                        # a failed call may have left counts behind

@@ -272,11 +272,10 @@ int cp2_masked_quantiles(const float* x, int64_t stride_row, int64_t stride_elem
 /* Up to 4 such problems in one call (NQ <= 4 quantiles q shared by all jobs).  Every argument of cp2_masked_quantiles
  * becomes a HOST array of njobs entries (device pointers inside).  Rows longer than CP2_QUANTILES_ROW_MAX are cut into
  * 8192-element chunks: three chunk-parallel histogram passes (12 + 10 + 10 bits) with a per-row select after each.
- * When every job has N <= CP2_QUANTILES_ROW_MAX the call is ONE launch and needs no workspace (NULL, 0): form 0 (default)
- * and 1 = one workgroup per row through all three levels; form 2 = one workgroup per 8192-element chunk with row-local
- * barriers (needs the zeroed workspace and at most 768 chunks in the call; 7 % faster at the training step's shapes, not
- * the default because of its spin-waits).  Identical results.  Rows longer than CP2_QUANTILES_ROW_MAX take the chunked
- * six-launch path (form 0), which needs:
+ * When every job has N <= CP2_QUANTILES_ROW_MAX the call is ONE launch (one workgroup per row through all three levels,
+ * the row held in registers) and needs no workspace (NULL, 0).  Rows longer than CP2_QUANTILES_ROW_MAX take the chunked
+ * six-launch path; there two consecutive jobs over the SAME logits with want = 1 and want = 0 (the reference's positive
+ * and negative dense scores) are served by ONE read of the logits per level.  That path needs:
  * workspace: device memory of cp2_quantiles_workspace_bytes(njobs, R, N, NQ) bytes, 16-byte aligned, ZERO before the
  * first call; every call leaves it zero again, so the same buffer serves every later call with the SAME (R, N, NQ).
  * mean_out: NULL, or a HOST array of njobs DEVICE pointers (NULL entries allowed): job j's row means [R] as torch's
@@ -286,7 +285,7 @@ int64_t cp2_quantiles_workspace_bytes(int njobs, const int* R, const int* N, int
 int cp2_masked_quantiles_multi(int njobs, const float* const* x, const int64_t* stride_row, const int64_t* stride_elem,
                                const int* R, const int* N, const float* const* mask_a, const float* const* mask_b,
                                const int* P, const int* want, const float* q, int NQ, float* const* out,
-                               float* const* mean_out, int form, void* workspace, int64_t workspace_bytes, void* stream);
+                               float* const* mean_out, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- f1: on-device two-crop augmentation + background erasing --- loader.py:39-43,50-118; main.py:204-225
  * One launch makes B output samples from a dataset resident in device memory: src [N,3,Hs,Ws] fp32 in [0,1]

@@ -65,11 +65,83 @@ class CpuCP2Step:
         return float(out["loss"].detach())
 
 
-def time_cpu_baseline(cfg, make_batch, b, h, w, K, steps=2, warmup=1, threads=None):
+class CpuDenseCLStep:
+    """BASELINE config 5: one DenseCL step (reference builder.py:667-999 with the flags of main.py:148-153 / scripts/
+    10-11-densecl.sh:33-52) on the CPU, assembled from the oracle's DenseCL functions: backbone + DenseCLNeck of both
+    encoders, EMA, shuffle, global loss vs `queue`, local loss vs `queue2` with the logits materialised as the reference
+    does, rank 0's score statistics (torch.quantile over every row's negatives, :776-786 / :875-886), both enqueues."""
+
+    def __init__(self, cfg, K=65536, dim=128, m=0.999, temperature=0.2, lmbd=0.5, lr=0.03, momentum=0.9, weight_decay=1e-4,
+                 seed=0, with_stats=True):
+        from cp2_amd.builder import DenseCLNeck              # plain torch.nn definition (reference builder.py:179-274)
+        torch.manual_seed(seed)
+        self.bb_q = build_segmentor(cfg.model).backbone
+        self.neck_q = DenseCLNeck(self.bb_q.feat_dim, 2048, dim)
+        self.bb_k, self.neck_k = copy.deepcopy(self.bb_q), copy.deepcopy(self.neck_q)
+        for p in list(self.bb_k.parameters()) + list(self.neck_k.parameters()):
+            p.requires_grad = False
+        self.neck_q.global_predictor.requires_grad_(False)      # unused without use_predictor (find_unused_parameters in the reference)
+        self.neck_q.local_predictor.requires_grad_(False)
+        self.queue = torch.nn.functional.normalize(torch.randn(dim, K), dim=0)
+        self.queue2 = torch.nn.functional.normalize(torch.randn(dim, K), dim=0)
+        self.ptr = self.ptr2 = 0
+        self.m, self.t, self.lmbd, self.with_stats = m, temperature, lmbd, with_stats
+        with torch.no_grad():
+            self.stride = 224 // self.bb_q(torch.rand(1, 3, 224, 224))[3].shape[2]
+        self.q_params = list(self.bb_q.parameters()) + list(self.neck_q.parameters())
+        self.k_params = list(self.bb_k.parameters()) + list(self.neck_k.parameters())
+        self.opt = torch.optim.SGD([p for p in self.q_params if p.requires_grad], lr, momentum=momentum, weight_decay=weight_decay)
+        self.split = {}
+
+    def step(self, batch):
+        tick = time.perf_counter
+        F = torch.nn.functional
+        t = [tick()]
+        ids_a, ids_b = O.strided_gather(batch["pixel_ids_a"], self.stride), O.strided_gather(batch["pixel_ids_b"], self.stride)
+        eq = self.bb_q(batch["img_a"])[3]
+        nq = self.neck_q(eq)
+        t.append(tick())
+        with torch.no_grad():
+            new = O.momentum_update([p.data for p in self.k_params], [p.data for p in self.q_params], self.m)
+            for p, v in zip(self.k_params, new):
+                p.data = v
+            t.append(tick())
+            perm = torch.randperm(eq.shape[0])
+            ek = self.bb_k(O.shuffle_take(batch["img_b"], perm, 0, 1))[3]
+            nk = self.neck_k(ek)
+            un = lambda x: O.unshuffle_take(x, perm, 0, 1)          # noqa: E731
+            ek, kl, kg, kp = un(ek), un(nk["x_local_proj"]), un(nk["x_global_proj"]), un(nk["x_avgpool_local_proj"])
+        t.append(tick())
+        qg, kg = F.normalize(nq["x_global_proj"], dim=1), F.normalize(kg, dim=1)
+        loss_g = O.densecl_global_loss(qg, kg, self.queue, self.t)
+        loss_l, _, neg, _ = O.densecl_local_loss(F.normalize(eq.flatten(2), dim=1), F.normalize(ek.flatten(2), dim=1),
+                                                 F.normalize(nq["x_local_proj"].flatten(2), dim=1), F.normalize(kl.flatten(2), dim=1),
+                                                 ids_a, ids_b, self.queue2, self.t, 0.0)
+        if self.with_stats:
+            with torch.no_grad():
+                qs = torch.tensor([0.25, 0.5, 0.75])
+                torch.quantile(neg, qs, dim=1), neg.mean(1), torch.quantile(qg @ self.queue, qs, dim=1)
+        loss = (1 - self.lmbd) * loss_g + self.lmbd * loss_l
+        t.append(tick())
+        self.queue, self.ptr = O.dequeue_and_enqueue(self.queue, self.ptr, kg.detach())
+        self.queue2, self.ptr2 = O.dequeue_and_enqueue(self.queue2, self.ptr2, F.normalize(kp, dim=1).detach())
+        t.append(tick())
+        self.opt.zero_grad()
+        loss.backward()
+        self.opt.step()
+        t.append(tick())
+        for name, a, b in zip(("query_fwd", "ema", "key_fwd", "loss_section", "enqueue", "backward_sgd"), t, t[1:]):
+            self.split[name] = self.split.get(name, 0.0) + (b - a)
+        return float(loss.detach())
+
+
+def time_cpu_baseline(cfg, make_batch, b, h, w, K, steps=2, warmup=1, threads=None, densecl=False, output_stride=16,
+                      temp_local=1.0, lmbd_dense=0.2):
     """images/sec of the CPU port on `threads` host threads (default: all)."""
     if threads:
         torch.set_num_threads(threads)
-    runner = CpuCP2Step(cfg, K=K)
+    runner = CpuDenseCLStep(cfg, K=K) if densecl else CpuCP2Step(cfg, K=K, output_stride=output_stride, temp_local=temp_local,
+                                                                 lmbd_dense=lmbd_dense)
     batches = [{k: v.cpu() for k, v in make_batch(b, h, w, "cpu", seed=100 + i).items()} for i in range(warmup + steps)]
     for i in range(warmup):
         runner.step(batches[i])

@@ -53,6 +53,9 @@ def test_bench_n1_line_has_the_contract_fields():
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in out, k
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["value"] > 0 and "comm" not in out
+    # the labels say what ran: ResNet-18 at 64x64 with a 1024-key queue is no BASELINE configuration
+    assert out["metric"] == "pretrain images/sec (whole node), ResNet-18 CP2 64^2, queue=1024"
+    assert out["config"]["workload"].startswith("custom sizes (not a BASELINE configuration): ResNet-18 + FCN(contrast) head OS16, 64x64")
     r = out["roofline"]
     assert r["bound"] == "hbm" and "sgd_flat_kernel" in r["kernel"] and r["bytes_per_slot_algorithmic"] == 20
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["bytes_fused"] >= r["bytes_algorithmic"]
@@ -81,12 +84,62 @@ def test_bench_two_ranks_one_device_without_a_launcher(exchange):
     ms = c["ms_per_step"]
     for k in ("c1_image_exchange", "c3_key_unshuffle", "c4_key_gather_enqueue", "step_without_grad_allreduce", "ddp_allreduce_exposed"):
         assert ms[k] is not None, k
-    assert ms["key_branch_wait_exposed"] is None           # default: one stream, nothing to wait for
-    assert c["grad_sync"] == "flat" and c["grad_buckets"] >= 1
+    # --overlap auto with peers: both forms were timed after the warm-up, the faster one (max over ranks) ran the timed region
+    cal = c["overlap_calibration"]
+    assert cal["steps_each"] >= 5 and set(cal["ms_per_step"]) == {"off", "gather"} and all(v > 0 for v in cal["ms_per_step"].values())
+    assert cal["chosen"] == min(cal["ms_per_step"], key=cal["ms_per_step"].get) == c["overlap_used"]
+    assert (ms["key_branch_wait_exposed"] is None) == (c["overlap_used"] == "off")    # one stream: nothing to wait for
+    pr = c["per_rank"]
+    assert len(pr["ms_per_step"]["by_rank"]) == 2 and pr["ms_per_step"]["max"] <= out["ms_per_step"] * 1.05
+    assert len(pr["host_issue_ms_per_step"]["by_rank"]) == 2 and pr["host_issue_ms_per_step"]["min"] > 0
+    assert c["grad_sync"] == "flat" and c["grad_buckets"] >= 1 and c["timeout_s"] == 120.0
     assert ms["c1_image_exchange"] > 0 and ms["c3_key_unshuffle"] > 0 and ms["c4_key_gather_enqueue"] > 0
     by = c["bytes_received_per_rank_per_step"]
     row = 3 * 64 * 64 * 2                                  # composed images travel in bf16 under bf16 autocast
     assert by["c1_image_exchange"] == (2 * row if exchange == "all_to_all" else 4 * row)
+
+
+def test_workload_labels_are_built_from_what_runs():
+    """--workload cfg2 | cfg4 | cfg5 pick the BASELINE configurations; explicit sizes drop the BASELINE label (round 3's cfg4
+    line carried cfg2's).  Parsed here without a GPU."""
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    old = sys.argv
+    try:
+        got = {}
+        for wl in ("cfg2", "cfg4", "cfg5"):
+            sys.argv = ["bench.py", "--workload", wl]
+            a = bench.parse()
+            got[wl] = (os.path.basename(a.config), a.img, a.queue, a.batch_per_gpu, a.densecl, a.as_baseline)
+        assert got["cfg2"] == ("config_pretrain_r50_fcn.py", 224, 65536, 32, False, True)
+        assert got["cfg4"] == ("config_pretrain_r101_d8.py", 512, 131072, 8, False, True)
+        assert got["cfg5"] == ("config_pretrain.py", 224, 65536, 32, True, True)       # scripts/10-11-densecl.sh:13
+        sys.argv = ["bench.py", "--workload", "cfg4", "--img", "256"]
+        assert bench.parse().as_baseline is False
+    finally:
+        sys.argv = old
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("wl,metric,kernel", [("cfg5", "ResNet-18 DenseCL 64^2, queue=1024", "rowkey"),
+                                              ("cfg4", "ResNet-18 CP2 64^2, queue=1024", "dense_bwd_kernel")])
+def test_bench_other_workloads_run_and_label_themselves(wl, metric, kernel):
+    """The cfg4 / cfg5 code paths of bench.py at toy sizes: the line names the method and sizes that ran and carries that
+    workload's roofline kernel and a CPU baseline of the same kind of step."""
+    argv = ["--gpus", "1", "--workload", wl, "--cpu-steps", "1", "--cpu-warmup", "0", "--cpu-batch", "2"] + SMALL
+    if wl == "cfg5":                # DenseCL needs a 2048-channel backbone (reference builder.py:408): ResNet-50, stride 32
+        argv = [a if a != SMALL[1] else os.path.join(ROOT, "configs", "config_moco.py") for a in argv]
+        metric = metric.replace("ResNet-18", "ResNet-50")
+        argv[argv.index("--batch-per-gpu") + 1] = "24"          # 24 x 4 = 96 rows: the many-rows kernel (R > 32)
+    res = _run(argv, timeout=850)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.strip()][-1])
+    assert out["metric"].endswith(metric), out["metric"]
+    assert kernel in out["roofline"]["kernel"] and out["roofline"]["bound"] == "mfma" and out["roofline"]["frac"] > 0
+    assert out["cpu_baseline"]["value"] > 0 and ("DenseCL" in out["cpu_baseline"]["sample"]) == (wl == "cfg5")
+    assert ("DenseCL" in out["config"]["workload"]) == (wl == "cfg5")
 
 
 @pytest.mark.gpu

@@ -102,6 +102,44 @@ def _worker(rank, world, port, out_dir):
         except RuntimeError as e:
             failed = "received no gradient" in str(e)
         assert failed
+        # a backward pass that raises half way (here: inside the first layers' backward, after the last layers' gradients
+        # have armed the reducer and started their all-reduce) leaves the reducer armed -- the engine skips its final
+        # callbacks: without reset(), which FlatDDP.forward calls, the next pass would not all-reduce at all and the replicas
+        # would drift apart silently
+        class Boom(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, t):
+                return t.clone()
+
+            @staticmethod
+            def backward(ctx, g):
+                raise RuntimeError("boom")
+        for p in params:
+            p.grad = None
+        try:
+            net[2:](Boom.apply(net[:2](xs[0]))).square().mean().backward()
+            boomed = False
+        except RuntimeError as e:
+            boomed = "boom" in str(e)
+        assert boomed and red._armed
+        red.reset()
+        assert not red._armed
+        for p in list(ref_net.parameters()) + params:
+            p.grad = None
+        x = torch.randn(4, 3, 6, 6, generator=torch.Generator().manual_seed(900 + rank))
+        ref(x).square().mean().backward()
+        net(x).square().mean().backward()
+        for a, b in zip(ref_net.parameters(), params):
+            assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-8)
+        # every rank planned the same bucket table; a rank with another table is named before the first backward pass
+        from cp2_amd import dist as cdist
+        cdist.assert_same_on_all_ranks("bucket table", red.table_hash())
+        try:
+            cdist.assert_same_on_all_ranks("bucket table", red.table_hash() + (1 if rank == world - 1 else 0))
+            mismatch = False
+        except RuntimeError as e:
+            mismatch = f"ranks [{world - 1}]" in str(e)
+        assert mismatch
         red.remove_hooks()
         torch.save({"ok": True, "w": params[0].detach().clone()}, os.path.join(out_dir, f"r{rank}.pt"))
         dist.barrier()

@@ -89,6 +89,51 @@ def test_world_n_gloo_collectives(tmp_path, world):
     assert torch.equal(q0[:, cols], want.t())
 
 
+def _hang_worker(rank, world, port, out_dir):
+    """Rank 1 never joins the second collective: rank 0's watchdog must name it and end the process with HANG_EXIT_CODE."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    cdist.init_process_group("gloo", rank, world, timeout_s=30, watchdog=False)
+    msgs = []
+    cdist.start_watchdog(1.5, poll_s=0.2, on_hang=msgs.append)
+    cdist.progress(0)
+    x = torch.ones(4) * rank
+    w = dist.all_reduce(x, async_op=True)
+    cdist.COLLECTIVES.note("c1_image_exchange", w)
+    w.wait()
+    cdist.progress(1)
+    if rank == 0:
+        w2 = dist.all_reduce(x, async_op=True)               # rank 1 never issues this one
+        cdist.COLLECTIVES.note("c3_key_unshuffle", w2)
+        import time
+        t0 = time.time()
+        while not msgs and time.time() - t0 < 20:
+            time.sleep(0.1)
+        with open(os.path.join(out_dir, "hang.txt"), "w") as f:
+            f.write(msgs[0] if msgs else "no message")
+        os._exit(0)                                          # the pending collective can never complete
+    else:
+        import time
+        time.sleep(6)
+        os._exit(0)
+
+
+@pytest.mark.timeout(120)
+def test_watchdog_names_the_collective_that_did_not_complete(tmp_path):
+    ctx = mp.spawn(_hang_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=False)
+    for p in ctx.processes:
+        p.join(60)
+    text = open(tmp_path / "hang.txt").read()
+    assert "rank 0 of 2 made no progress" in text and "at step 1" in text
+    assert "first collective not completed: c3_key_unshuffle (step 1)" in text
+
+
+def test_shuffle_plan_refuses_a_table_that_is_no_permutation():
+    with pytest.raises(ValueError, match="not a permutation"):
+        cdist.ShufflePlan(torch.tensor([0, 1, 1, 3]), 0, 2)
+    with pytest.raises(ValueError, match="not a permutation"):
+        cdist.ShufflePlan(torch.tensor([0, 1, 2, 7]), 0, 2)
+
+
 def test_single_process_helpers_without_process_group():
     x = torch.randn(4, 3)
     assert cdist.world_size() == 1 and cdist.rank() == 0

@@ -313,26 +313,20 @@ def test_rowkey_large_split_property():
     grad_close(got.dE[:, 0], p_cpu.grad, "slice d pos")
 
 
-@pytest.mark.parametrize("form", [0, 2], ids=["workgroup-per-row", "chunk-cooperative"])
-def test_masked_quantiles_bit_exact_vs_torch(form):
+def test_masked_quantiles_bit_exact_vs_torch():
     """Same input -> the radix-select quantiles equal torch.quantile / torch.nanquantile bit for bit
-    (the reference's convention, tests/test_contrastive_metrics.py:50-57).  Both one-launch forms for rows up to 131072
-    elements: a workgroup per row (the product path) and a workgroup per chunk with row-local barriers (DESIGN.md section
-    4), plus the row means torch's x.mean(1) gives."""
-    old = ops.QUANTILES_FORM
-    ops.QUANTILES_FORM = form
-    try:
-        _masked_quantiles_cases()
-        gen = torch.Generator().manual_seed(8)
-        x = torch.randn(6, 70_001, generator=gen)
-        x[2, 17] = float("nan")
-        means = torch.empty(6, device=DEV)
-        q = ops.masked_quantiles_multi([dict(x=x.to(DEV), stride_row=70_001, stride_elem=1, R=6, N=70_001, mean_out=means)])[0]
-        assert np.array_equal(q.cpu().numpy(), torch.nanquantile(x, torch.tensor([0.25, 0.5, 0.75]), dim=1).numpy(), equal_nan=True)
-        want = x.double().mean(1).float()
-        assert torch.isnan(means[2]) and (means.cpu()[[0, 1, 3, 4, 5]] - want[[0, 1, 3, 4, 5]]).abs().max() <= 1e-6
-    finally:
-        ops.QUANTILES_FORM = old
+    (the reference's convention, tests/test_contrastive_metrics.py:50-57): the one-launch row kernel for rows up to 131072
+    elements, the chunked six-launch form above (with the positive / negative classes of one logit map served by one read
+    per level), plus the row means torch's x.mean(1) gives."""
+    _masked_quantiles_cases()
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn(6, 70_001, generator=gen)
+    x[2, 17] = float("nan")
+    means = torch.empty(6, device=DEV)
+    q = ops.masked_quantiles_multi([dict(x=x.to(DEV), stride_row=70_001, stride_elem=1, R=6, N=70_001, mean_out=means)])[0]
+    assert np.array_equal(q.cpu().numpy(), torch.nanquantile(x, torch.tensor([0.25, 0.5, 0.75]), dim=1).numpy(), equal_nan=True)
+    want = x.double().mean(1).float()
+    assert torch.isnan(means[2]) and (means.cpu()[[0, 1, 3, 4, 5]] - want[[0, 1, 3, 4, 5]]).abs().max() <= 1e-6
 
 
 def _masked_quantiles_cases():
@@ -396,6 +390,22 @@ def _masked_quantiles_cases():
         pos, neg = ops.masked_quantiles_multi(jobs)
         assert np.array_equal(pos.cpu().numpy(), st["positive"]["quartiles"].numpy(), equal_nan=True)
         assert np.array_equal(neg.cpu().numpy(), st["negative"]["quartiles"].numpy(), equal_nan=True)
+    # chunked form, pairing rules: (want=1, want=0) over the same map = one read per level; the reverse order, a lone class
+    # and a pair next to an unmasked long-row job take the unpaired path / mix both -- all must agree with the oracle
+    B, P = 2, 400
+    logits = torch.randn(B, P, P, generator=gen) * 0.05 + 0.8
+    ma = (torch.rand(B, P, generator=gen) > 0.3).float()
+    mb = (torch.rand(B, P, generator=gen) > 0.6).float()
+    st = O.dense_loss_stats(logits, ma[:, :, None] * mb[:, None, :])
+    lneg = torch.randn(3, 140_000, generator=gen)
+    wq = torch.quantile(lneg, torch.tensor([0.25, 0.5, 0.75]), dim=1)
+    job = lambda w: dict(x=logits.to(DEV), stride_row=P * P, stride_elem=1, R=B, N=P * P, mask_a=ma.to(DEV), mask_b=mb.to(DEV), want=w)  # noqa: E731
+    long_job = dict(x=lneg.to(DEV), stride_row=140_000, stride_elem=1, R=3, N=140_000)
+    for order in ((1, 0), (0, 1), (1,), (0,), (1, 0, "long"), ("long", 1, 0)):
+        outs = ops.masked_quantiles_multi([long_job if w == "long" else job(w) for w in order])
+        for w, o in zip(order, outs):
+            want = wq if w == "long" else st["positive" if w == 1 else "negative"]["quartiles"]
+            assert np.array_equal(o.cpu().numpy(), want.numpy(), equal_nan=True), (order, w)
     B, P = 3, 37
     logits = torch.randn(B, P, P, generator=gen)
     ma = (torch.rand(B, P, generator=gen) > 0.4).float()

@@ -24,7 +24,8 @@ def _free_port():
 
 
 def _worker(rank, port, out_dir, grad_sync):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)       # cdist.init_process_group must put it there itself
     import sys
     sys.path.insert(0, ROOT)
     from cp2_amd import builder, dist as cdist, synthetic
@@ -33,10 +34,9 @@ def _worker(rank, port, out_dir, grad_sync):
     from cp2_amd.pretrain_types import PretrainType
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
-    dist.init_process_group("nccl", rank=0, world_size=1)
+    cdist.init_process_group("nccl", 0, 1, timeout_s=100)    # a one-rank group: every exchange step of the N > 1 path is issued
     try:
-        assert dist.get_backend() == "nccl"
-        cdist.FORCE_COLLECTIVES = True                       # every all-gather / broadcast / side-stream branch runs on RCCL
+        assert dist.get_backend() == "nccl" and cdist.multi() and os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
         x = torch.arange(24, dtype=torch.float32, device=dev).reshape(6, 4)
         out = torch.empty_like(x)
         dist.all_gather_into_tensor(out, x)                  # the branch dist.concat_all_gather takes on RCCL
@@ -91,6 +91,10 @@ def _worker(rank, port, out_dir, grad_sync):
             losses.append(float(loss))
         torch.cuda.synchronize()
         assert all(l == l for l in losses) and int(model.queue_ptr) == 36 and model._side_stream is not None
+        # every exchange step went through the collective log (what the hang watchdog reads), all of them completed
+        names = " | ".join(n for _, n, _ in cdist.COLLECTIVES.items)
+        assert "all_to_all" in names and "all_gather" in names and (grad_sync != "flat" or "c5 gradient all-reduce, bucket" in names)
+        assert cdist.COLLECTIVES.first_incomplete() is None
         torch.save({"losses": losses}, os.path.join(out_dir, "nccl.pt"))
     finally:
         dist.destroy_process_group()
