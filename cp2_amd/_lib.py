@@ -7,7 +7,8 @@ import re
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcp2hip.so")
+# CP2HIP_LIB: another build of the same library (kernel experiments under tools/); it must export the same symbols
+LIB_PATH = os.environ.get("CP2HIP_LIB") or os.path.join(_HERE, "lib", "libcp2hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "cp2hip.h")
 
 _P = c_void_p  # every device pointer crosses the ABI as a plain address

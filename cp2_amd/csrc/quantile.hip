@@ -125,7 +125,11 @@ __device__ __forceinline__ void chunk_load(const QuantArgs& a, int r, int begin,
 // (mask_a[x] * mask_b[y] != 0), 0 for a negative pair or an unmasked job.  The caller filters by class.
 template <int NT, typename F>
 __device__ __forceinline__ void chunk_visit(const QuantArgs& a, int r, int begin, int end, const ChunkData<NT>& d, F&& f) {
+#if defined(QEXP) && QEXP == 3
+    const bool masked = false;
+#else
     const bool masked = a.want >= 0;
+#endif
     const float* ma = masked ? a.mask_a + (int64_t)r * a.P : nullptr;
     const float* mb = masked ? a.mask_b + (int64_t)r * a.P : nullptr;
     if (!d.vec) {                                          // strided or unaligned rows: element by element
@@ -253,9 +257,15 @@ __global__ __launch_bounds__(QT1) void quantile_hist_kernel(QuantJobs jobs) {
     for (int i = tid; i < nside * NB; i += QT1) h[i] = 0;
     if (LEVEL == 2 && tid < 2 * QMAX) sh_min[tid] = QNONE;
     __syncthreads();
+#ifdef QEXP
+    unsigned dummy = 0;
+#endif
     chunk_visit<QT1>(a, r, begin, end, d, [&](unsigned k, int cls) {
         const int sd = side_of_cls[cls];
         if (sd < 0) return;
+#if defined(QEXP) && QEXP == 1
+        dummy ^= k + (unsigned)sd; return;
+#endif
         if (LEVEL == 0) {
             atomicAdd(&h[sd * NB + (k >> 20)], 1u);
         } else {
@@ -285,6 +295,12 @@ __global__ __launch_bounds__(QT1) void quantile_hist_kernel(QuantJobs jobs) {
         }
     }
     __syncthreads();
+#ifdef QEXP
+    if (dummy == 0x12345678u) h[0] = dummy;
+#if QEXP == 2
+    return;
+#endif
+#endif
     for (int sd = 0; sd < nside; ++sd) {
         if (!live[sd]) continue;
         if (LEVEL == 0) {
