@@ -38,7 +38,7 @@ struct QuantArgs {
     const float* q; int NQ;
     float* out;                                            // [NQ][R] (torch.quantile layout)
     int R;
-    int chunks;                                            // ceil(N / QCHUNK)
+    int chunks;                                            // chunk workgroups per row: ceil(ceil(N / QCHUNK) / QCPW)
     float* mean_out;                                       // NULL, or [R]: mean of the row as torch's x.mean(1) (NaN if the row holds one); want < 0, row kernel only
     int pair;                                              // chunked form: 1 = this job (want 1) and the next one (want 0) read the same logits:
                                                            // its chunk workgroups fill both jobs' histograms from ONE read; 2 = that next job
@@ -54,7 +54,8 @@ __device__ __forceinline__ float key2f(unsigned k) {
 
 constexpr int QMAX = 4;                   // quantiles per call
 constexpr int QB0 = 4096, QB1 = 1024;     // bins of the first / second and third level
-constexpr int QCHUNK = 8192;              // elements per workgroup of the chunk-parallel passes
+constexpr int QCHUNK = 8192;              // elements per chunk of the chunk-parallel passes (one set of loads in flight)
+constexpr int QCPW = 4;                   // chunks per workgroup of those passes
 constexpr int QT1 = 256;                  // threads per workgroup of the chunk-parallel passes
 constexpr int QT3 = 1024;                 // threads per workgroup of the per-row kernels
 constexpr int QJOBS = 4;
@@ -92,20 +93,58 @@ __device__ __forceinline__ unsigned block_scan_incl(unsigned v, unsigned* wtot) 
     return incl + base;
 }
 
+// Histogram adds of FOUR consecutive elements per lane (one 16-byte load) for a converged 64-lane wavefront (row kernel).
+// Narrow-band rows put most of a wavefront's 256 elements into one or two bins, and 64 lanes adding to one LDS address
+// serialise.  Probe: lane 0's bin of slot 0 is broadcast and counted over slot 0 (one ballot); a spread-out row fails the
+// probe (fewer than a quarter of the lanes) and every lane adds for itself, as before.  Otherwise
+// the bin is counted over all four slots and ONE lane adds the count (a freshly initialised encoder -- every logit within a
+// few ulps of 1 -- ends here: one add per 256 elements); the same is done once more for the bin of the first element still
+// pending (the positive scores of a trained encoder: two hot first-level bins), and only the stragglers add for themselves.
+__device__ __forceinline__ void hist_add4_wave(unsigned* h, const unsigned (&bin)[4], const bool (&pred)[4]) {
+    const int lane = threadIdx.x & 63;
+    bool pend[4] = {pred[0], pred[1], pred[2], pred[3]};
+    // (lane 0's element stands for "the first wanted one": if it is not wanted the probe merely fails)
+    const unsigned b0 = (unsigned)__builtin_amdgcn_readfirstlane((int)bin[0]);
+    if (__popcll(__ballot(pend[0] && bin[0] == b0)) >= 16) {
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+            const unsigned long long m0 = __ballot(pend[0]), m1 = __ballot(pend[1]), m2 = __ballot(pend[2]), m3 = __ballot(pend[3]);
+            const int total = __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+            if (total == 0) return;
+            unsigned b;
+            if (m0) b = (unsigned)__builtin_amdgcn_readlane((int)bin[0], __ffsll((long long)m0) - 1);
+            else if (m1) b = (unsigned)__builtin_amdgcn_readlane((int)bin[1], __ffsll((long long)m1) - 1);
+            else if (m2) b = (unsigned)__builtin_amdgcn_readlane((int)bin[2], __ffsll((long long)m2) - 1);
+            else b = (unsigned)__builtin_amdgcn_readlane((int)bin[3], __ffsll((long long)m3) - 1);
+            const bool e0 = pend[0] && bin[0] == b, e1 = pend[1] && bin[1] == b, e2 = pend[2] && bin[2] == b, e3 = pend[3] && bin[3] == b;
+            const int cnt = __popcll(__ballot(e0)) + __popcll(__ballot(e1)) + __popcll(__ballot(e2)) + __popcll(__ballot(e3));
+            if (cnt < 64 && cnt < total) break;             // not a hot bin: everyone for themselves
+            if (lane == 0) atomicAdd(&h[b], (unsigned)cnt);
+            if (cnt == total) return;
+            pend[0] = pend[0] && !e0; pend[1] = pend[1] && !e1; pend[2] = pend[2] && !e2; pend[3] = pend[3] && !e3;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (pend[u]) atomicAdd(&h[bin[u]], 1u);
+}
+
 // One chunk (QCHUNK elements = 8 float4 per thread of a 256-thread workgroup), split into "issue every load" and
-// "process": K1 / K2 put all global loads of a workgroup (data and histograms) in flight at once, so a workgroup pays ONE
-// memory round trip instead of one per loop iteration.
+// "process": the passes put all global loads of a workgroup (data, mask values, histograms) in flight at once, so a
+// workgroup pays ONE memory round trip instead of one per loop iteration.
 template <int NT>
 struct ChunkData {
     static constexpr int G = QCHUNK / (NT * 4);
     float4 v[G];
-    bool vec;
+    float4 mb4[G]; float fa[G];                            // masked jobs with P % 4 == 0: mask_b of the four elements, mask_a of their x
+    bool vec, mvec;
 };
 
 template <int NT>
 __device__ __forceinline__ void chunk_load(const QuantArgs& a, int r, int begin, int end, ChunkData<NT>& d) {
     const float* row = a.x + (int64_t)r * a.s_row;
     d.vec = a.s_elem == 1 && ((reinterpret_cast<uintptr_t>(row) & 15u) == 0);
+    d.mvec = false;
     if (!d.vec) return;
 #pragma unroll
     for (int g = 0; g < ChunkData<NT>::G; ++g) {
@@ -119,70 +158,73 @@ __device__ __forceinline__ void chunk_load(const QuantArgs& a, int r, int begin,
             d.v[g].w = NAN;
         }
     }
+    if (a.want >= 0) {
+        const float* ma = a.mask_a + (int64_t)r * a.P;
+        const float* mb = a.mask_b + (int64_t)r * a.P;
+        d.mvec = (a.P & 3) == 0 && ((reinterpret_cast<uintptr_t>(mb) & 15u) == 0);
+        if (d.mvec) {
+            // (x, y) of a group's first element: begin + loc = x * P + y; the four elements of a group share x (P % 4 == 0)
+            const int x0 = begin / a.P, rem0 = begin - x0 * a.P;
+            const float invP = 1.0f / (float)a.P;
+#pragma unroll
+            for (int g = 0; g < ChunkData<NT>::G; ++g) {
+                const int t = rem0 + (g * NT + (int)threadIdx.x) * 4;       // < P + QCHUNK: exact through a float quotient and one correction
+                int dx = (int)((float)t * invP);
+                if (dx * a.P > t) --dx; else if ((dx + 1) * a.P <= t) ++dx;
+                const int x_ = x0 + dx, y_ = t - dx * a.P;
+                const bool in = x_ < a.P;
+                d.fa[g] = in ? ma[x_] : 0.f;
+                d.mb4[g] = in ? *reinterpret_cast<const float4*>(mb + y_) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
 }
 
-// Visit the elements of one chunk: f(key, cls) for every non-NaN element, cls = 1 for a positive pair
-// (mask_a[x] * mask_b[y] != 0), 0 for a negative pair or an unmasked job.  The caller filters by class.
-template <int NT, typename F>
-__device__ __forceinline__ void chunk_visit(const QuantArgs& a, int r, int begin, int end, const ChunkData<NT>& d, F&& f) {
-#if defined(QEXP) && QEXP == 3
-    const bool masked = false;
-#else
+// key[u] / cls[u] of the four elements of the thread's group g (vec chunks): cls 1 = positive pair (mask_a[x] * mask_b[y] != 0),
+// 0 = negative pair or unmasked job, -1 = not an element (NaN, beyond the row's end)
+template <int NT>
+__device__ __forceinline__ void chunk_classify(const QuantArgs& a, int r, int begin, int end, const ChunkData<NT>& d, int g,
+                                               unsigned (&key)[4], int (&cls)[4]) {
     const bool masked = a.want >= 0;
-#endif
+    const int loc = (g * NT + (int)threadIdx.x) * 4, i = begin + loc;
+    const float vv[4] = {d.v[g].x, d.v[g].y, d.v[g].z, d.v[g].w};
+    if (!masked) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { key[u] = f2key(vv[u]); cls[u] = (i + u < end && vv[u] == vv[u]) ? 0 : -1; }
+    } else if (d.mvec) {
+        const float mm[4] = {d.mb4[g].x, d.mb4[g].y, d.mb4[g].z, d.mb4[g].w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            key[u] = f2key(vv[u]);
+            cls[u] = (i + u < end && vv[u] == vv[u]) ? (((d.fa[g] * mm[u]) != 0.f) ? 1 : 0) : -1;
+        }
+    } else {
+        const float* ma = a.mask_a + (int64_t)r * a.P;
+        const float* mb = a.mask_b + (int64_t)r * a.P;
+        int x_ = i / a.P, y_ = i - x_ * a.P;
+        float fa = x_ < a.P ? ma[x_] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            key[u] = f2key(vv[u]);
+            cls[u] = (i + u < end && vv[u] == vv[u]) ? (((fa * (x_ < a.P ? mb[y_] : 0.f)) != 0.f) ? 1 : 0) : -1;
+            if (++y_ >= a.P) { y_ = 0; ++x_; fa = (x_ < a.P) ? ma[x_] : 0.f; }
+        }
+    }
+}
+
+// Strided or unaligned rows: element by element, f(key, cls) for every non-NaN element.
+template <int NT, typename F>
+__device__ __forceinline__ void chunk_visit_scalar(const QuantArgs& a, int r, int begin, int end, F&& f) {
+    const bool masked = a.want >= 0;
     const float* ma = masked ? a.mask_a + (int64_t)r * a.P : nullptr;
     const float* mb = masked ? a.mask_b + (int64_t)r * a.P : nullptr;
-    if (!d.vec) {                                          // strided or unaligned rows: element by element
-        const float* row = a.x + (int64_t)r * a.s_row;
-        for (int i = begin + (int)threadIdx.x; i < end; i += NT) {
-            const float v = row[(int64_t)i * a.s_elem];
-            if (v != v) continue;
-            int cls = 0;
-            if (masked) { const int x_ = i / a.P; cls = ((ma[x_] * mb[i - x_ * a.P]) != 0.f) ? 1 : 0; }
-            f(f2key(v), cls);
-        }
-        return;
-    }
-    int x0 = 0, rem0 = 0;
-    float invP = 0.f;
-    bool mvec = false;
-    if (masked) {
-        x0 = begin / a.P; rem0 = begin - x0 * a.P; invP = 1.0f / (float)a.P;       // uniform: scalar unit
-        mvec = (a.P & 3) == 0 && ((reinterpret_cast<uintptr_t>(mb) & 15u) == 0);
-    }
-#pragma unroll
-    for (int g = 0; g < ChunkData<NT>::G; ++g) {
-        const int loc = (g * NT + (int)threadIdx.x) * 4, i = begin + loc;
-        if (i >= end) break;
-        const float vv[4] = {d.v[g].x, d.v[g].y, d.v[g].z, d.v[g].w};
-        if (!masked) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) if (vv[u] == vv[u]) f(f2key(vv[u]), 0);
-            continue;
-        }
-        // (x, y) of element i: rem0 + loc < P + QCHUNK, exact through a float quotient and one correction
-        const int t = rem0 + loc;
-        int dx = (int)((float)t * invP);
-        if (dx * a.P > t) --dx; else if ((dx + 1) * a.P <= t) ++dx;
-        int x_ = x0 + dx, y_ = t - dx * a.P;
-        if (mvec) {                                        // P % 4 == 0: the four elements share x, mask_b as one load
-            const float fa = x_ < a.P ? ma[x_] : 0.f;
-            const float4 m4 = x_ < a.P ? *reinterpret_cast<const float4*>(mb + y_) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float mm[4] = {m4.x, m4.y, m4.z, m4.w};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float v = vv[u];
-                if (v == v) f(f2key(v), ((fa * mm[u]) != 0.f) ? 1 : 0);
-            }
-        } else {
-            float fa = x_ < a.P ? ma[x_] : 0.f;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float v = vv[u];
-                if (v == v) f(f2key(v), ((fa * mb[y_]) != 0.f) ? 1 : 0);
-                if (++y_ >= a.P) { y_ = 0; ++x_; fa = (x_ < a.P) ? ma[x_] : 0.f; }
-            }
-        }
+    const float* row = a.x + (int64_t)r * a.s_row;
+    for (int i = begin + (int)threadIdx.x; i < end; i += NT) {
+        const float v = row[(int64_t)i * a.s_elem];
+        if (v != v) continue;
+        int c = 0;
+        if (masked) { const int x_ = i / a.P; c = ((ma[x_] * mb[i - x_ * a.P]) != 0.f) ? 1 : 0; }
+        f(f2key(v), c);
     }
 }
 
@@ -213,12 +255,19 @@ __device__ __forceinline__ void locate(const unsigned (&hv)[BPT], unsigned excl,
 // the selected first-level bin; 2: last 10 bits of the elements with the selected 22-bit prefix + smallest key above it).
 // A chunk of a PAIRED job (QuantArgs::pair == 1: the positive and the negative class of one logit map) is read once and
 // every element goes to the histograms of its own class (side 0 = this job's row, side 1 = the next job's row).
-// Quantiles whose prefix so far is equal share one LDS histogram (on the narrow-band rows of a young encoder all three
-// quartiles sit in one bin: one LDS add per element instead of three); the flush adds it to each of their global ones.
+// Quantiles whose prefix so far is equal share one LDS histogram; the flush adds it to each of their global ones.
+//
+// What bounds these passes (round 4, rocprofv3 --pmc on the config-4 shape): not the LDS atomics and not HBM but VALU
+// instructions -- the first version spent 48 (level 0) to 128 (levels 1, 2) vector instructions per element slot, 270 M
+// wave instructions per launch = 0.5 ms on the chip's 1024 SIMDs, whatever the data.  Hence the shape of the loop below:
+// an element's class is folded into its key once ("extended top" = prefix bits, class bit), every table the loop
+// compares with is wave-uniform (scalar registers), a level-1 / 2 element costs one compare and one select per DISTINCT
+// live prefix, and the LDS histogram is cleared and flushed with 16-byte accesses.
 template <int LEVEL>
 __global__ __launch_bounds__(QT1) void quantile_hist_kernel(QuantJobs jobs) {
     constexpr int NB = LEVEL == 0 ? QB0 : QMAX * QB1;
-    __shared__ unsigned h[2 * NB];
+    constexpr unsigned NEVERX = 0xFFFFFFFFu;               // no extended top has this value (tops have at most 22 bits)
+    __shared__ __attribute__((aligned(16))) unsigned h[2 * NB];
     __shared__ unsigned sh_min[2 * QMAX];
     const int jsel = job_of(jobs.first_chunk, (int)blockIdx.x);
     const QuantArgs& a = jobs.job[jsel];
@@ -229,80 +278,122 @@ __global__ __launch_bounds__(QT1) void quantile_hist_kernel(QuantJobs jobs) {
     const int64_t rt[2] = {jobs.first_row[jsel] + r, pair ? jobs.first_row[jsel + 1] + r : 0};
     const unsigned* sel[2] = {jobs.sel + rt[0] * QSEL, jobs.sel + rt[1] * QSEL};
     bool live[2] = {true, pair};
-    if (LEVEL > 0) {
-        live[0] = sel[0][0] != 0u;
-        live[1] = pair && sel[1][0] != 0u;
+    if (LEVEL > 0) {                                       // (readfirstlane: loaded values, uniform by construction -> scalar registers)
+        live[0] = __builtin_amdgcn_readfirstlane((int)sel[0][0]) != 0;
+        live[1] = pair && __builtin_amdgcn_readfirstlane((int)sel[1][0]) != 0;
         if (!live[0] && !live[1]) return;                  // nothing kept in this row (workgroup-uniform)
     }
-    const int begin = s * QCHUNK, end = min(a.N, begin + QCHUNK);
-    ChunkData<QT1> d;
-    chunk_load<QT1>(a, r, begin, end, d);                  // every load of the workgroup in flight
-    // class -> side: unpaired masked job: only class `want` counts (side 0); paired: positives side 0, negatives side 1
-    const int side_of_cls[2] = {pair ? 1 : ((a.want < 0 || a.want == 0) ? 0 : -1), pair ? 0 : ((a.want < 0 || a.want == 1) ? 0 : -1)};
-    unsigned pre[2][QMAX], eff[2][QMAX], mn[2][QMAX];
-    int slot[2][QMAX];
+    // class (0: negative pair / unmasked, 1: positive pair) -> side, or -1 when the class is not counted by this job
+    int side_of[2];
+    side_of[0] = pair ? 1 : ((a.want < 0 || a.want == 0) ? 0 : -1);
+    side_of[1] = pair ? 0 : ((a.want < 0 || a.want == 1) ? 0 : -1);
+    // per class: distinct live prefixes as extended tops, the LDS base of their histogram, and (level 2) the first key above
+    unsigned effx[2][QMAX], hi1[2][QMAX], pre[2][QMAX];
+    int hbase[2][QMAX], slot[2][QMAX];
 #pragma unroll
-    for (int sd = 0; sd < 2; ++sd) {
+    for (int cl = 0; cl < 2; ++cl) {
+        const int sd = side_of[cl];
 #pragma unroll
         for (int j = 0; j < QMAX; ++j) {
-            pre[sd][j] = (LEVEL > 0 && j < NQ && live[sd]) ? sel[sd][1 + 2 * j] : QNONE;
-            slot[sd][j] = j;
+            const bool on = LEVEL > 0 && j < NQ && sd >= 0 && live[sd < 0 ? 0 : sd];
+            pre[cl][j] = on ? (unsigned)__builtin_amdgcn_readfirstlane((int)sel[sd][1 + 2 * j]) : QNONE;
+            slot[cl][j] = j;
 #pragma unroll
             for (int i = j - 1; i >= 0; --i)
-                if (pre[sd][i] == pre[sd][j]) slot[sd][j] = i;
-            eff[sd][j] = slot[sd][j] == j ? pre[sd][j] : QNONE;      // a duplicate prefix counts in the first one's histogram
-            mn[sd][j] = QNONE;
+                if (pre[cl][i] == pre[cl][j]) slot[cl][j] = i;
+            const bool first = on && slot[cl][j] == j;     // a duplicate prefix counts in the first one's histogram
+            effx[cl][j] = first ? ((pre[cl][j] << 1) | (unsigned)cl) : NEVERX;
+            hbase[cl][j] = (sd < 0 ? 0 : sd) * NB + j * QB1;
+            // smallest key above the prefix as min over (k - hi1) mod 2^32 (see qrow_body_cached): hi1 = first key above its range
+            hi1[cl][j] = (LEVEL == 2 && first) ? ((pre[cl][j] << 10) | (unsigned)(QB1 - 1)) + 1u : 0u;
         }
     }
-    for (int i = tid; i < nside * NB; i += QT1) h[i] = 0;
+    unsigned mn[2][QMAX];
+#pragma unroll
+    for (int cl = 0; cl < 2; ++cl)
+#pragma unroll
+        for (int j = 0; j < QMAX; ++j) mn[cl][j] = NEVERX;
+    {
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        for (int i = tid; i < nside * NB / 4; i += QT1) reinterpret_cast<uint4*>(h)[i] = z;
+    }
     if (LEVEL == 2 && tid < 2 * QMAX) sh_min[tid] = QNONE;
     __syncthreads();
-#ifdef QEXP
-    unsigned dummy = 0;
-#endif
-    chunk_visit<QT1>(a, r, begin, end, d, [&](unsigned k, int cls) {
-        const int sd = side_of_cls[cls];
-        if (sd < 0) return;
-#if defined(QEXP) && QEXP == 1
-        dummy ^= k + (unsigned)sd; return;
-#endif
+    // element -> histogram index (or -1: not counted); level 2 also tracks the smallest key above every live prefix
+    auto index_of = [&](unsigned k, int cl) -> int {       // cl: 0 / 1, or -1 = not an element
         if (LEVEL == 0) {
-            atomicAdd(&h[sd * NB + (k >> 20)], 1u);
-        } else {
-            const unsigned top = LEVEL == 1 ? (k >> 20) : (k >> 10);
-            const unsigned bin = LEVEL == 1 ? ((k >> 10) & (QB1 - 1)) : (k & (QB1 - 1));
+            const int sd = cl < 0 ? -1 : (cl ? side_of[1] : side_of[0]);
+            return sd < 0 ? -1 : sd * NB + (int)(k >> 20);
+        }
+        constexpr int SH = LEVEL == 1 ? 20 : 10;
+        const unsigned topx = cl < 0 ? NEVERX : (((k >> SH) << 1) | (unsigned)cl);
+        int idx = -1;
 #pragma unroll
-            for (int j = 0; j < QMAX; ++j) {
-                const unsigned e = sd ? eff[1][j] : eff[0][j];
-                if (top == e) atomicAdd(&h[sd * NB + j * QB1 + bin], 1u);
-                if (LEVEL == 2) {
-                    const unsigned p = sd ? pre[1][j] : pre[0][j];
-                    if (p != QNONE && top > p) { if (sd) mn[1][j] = min(mn[1][j], k); else mn[0][j] = min(mn[0][j], k); }
-                }
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int j = 0; j < QMAX; ++j)
+                if (effx[c2][j] != NEVERX && topx == effx[c2][j]) idx = hbase[c2][j];      // first test: scalar, skips dead entries
+        if (LEVEL == 2) {
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                const unsigned kc = cl == c2 ? k : NEVERX;     // elements of the other class (or none) are neutral for the minimum
+#pragma unroll
+                for (int j = 0; j < QMAX; ++j)
+                    if (effx[c2][j] != NEVERX) mn[c2][j] = min(mn[c2][j], kc - hi1[c2][j]);
             }
         }
-    });
+        return idx < 0 ? -1 : idx + (int)((k >> (SH - 10)) & (QB1 - 1));
+    };
+    // QCPW consecutive chunks per workgroup: the LDS histogram is cleared and flushed (global atomics, the dearest part of a
+    // spread-out row's pass) once per 32768 elements
+    for (int cc = 0; cc < QCPW; ++cc) {
+        const int begin = (s * QCPW + cc) * QCHUNK, end = min(a.N, begin + QCHUNK);
+        if (begin >= a.N) break;
+        ChunkData<QT1> d;
+        chunk_load<QT1>(a, r, begin, end, d);              // every load of the chunk in flight
+        if (d.vec) {
+#pragma unroll
+            for (int g = 0; g < ChunkData<QT1>::G; ++g) {
+                unsigned key[4];
+                int cl[4];
+                chunk_classify<QT1>(a, r, begin, end, d, g, key, cl);
+                // one LDS atomic per element: measured against a one-lane add of a hot bin's count (hist_add4_wave, what the row
+                // kernel uses) these passes are 20-35 % faster WITHOUT it on every distribution -- they are bound by vector
+                // instructions and by the LDS atomic rate (about one lane per clock and CU), not by same-address conflicts
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ix = index_of(key[u], cl[u]);
+                    if (ix >= 0) atomicAdd(&h[ix], 1u);
+                }
+            }
+        } else {
+            chunk_visit_scalar<QT1>(a, r, begin, end, [&](unsigned k, int c2) {
+                const int ix = index_of(k, c2);
+                if (ix >= 0) atomicAdd(&h[ix], 1u);
+            });
+        }
+    }
     if (LEVEL == 2) {
 #pragma unroll
-        for (int sd = 0; sd < 2; ++sd) {
+        for (int cl = 0; cl < 2; ++cl) {
+            const int sd = side_of[cl];
 #pragma unroll
             for (int j = 0; j < QMAX; ++j) {
-                unsigned m = mn[sd][j];
+                if (effx[cl][j] == NEVERX) continue;       // scalar
+                unsigned m = mn[cl][j];
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, off, 64));
-                if ((tid & 63) == 0 && m != QNONE) atomicMin(&sh_min[sd * QMAX + j], m);
+                const unsigned kmin = m + hi1[cl][j];      // back to a key; below hi1 = wrapped = nothing above the prefix
+                if ((tid & 63) == 0 && kmin >= hi1[cl][j] && kmin != NEVERX) atomicMin(&sh_min[sd * QMAX + j], kmin);
             }
         }
     }
     __syncthreads();
-#ifdef QEXP
-    if (dummy == 0x12345678u) h[0] = dummy;
-#if QEXP == 2
-    return;
-#endif
-#endif
     for (int sd = 0; sd < nside; ++sd) {
         if (!live[sd]) continue;
+        const int cl = side_of[0] == sd ? 0 : 1;           // the class this side counts (an unmasked job: class 0)
+        // lanes add CONSECUTIVE bins: a wave instruction's atomics fall into 256 contiguous bytes (one lane per 16 bytes
+        // quadruples the memory-side requests: measured 274 -> 600 us for the first-level pass)
         if (LEVEL == 0) {
             unsigned* g = jobs.hist0 + rt[sd] * QB0;
             for (int i = tid; i < QB0; i += QT1) {
@@ -312,14 +403,17 @@ __global__ __launch_bounds__(QT1) void quantile_hist_kernel(QuantJobs jobs) {
         } else {
             unsigned* g = (LEVEL == 1 ? jobs.hist1 : jobs.hist2) + rt[sd] * QMAX * QB1;
             for (int j = 0; j < NQ; ++j) {
-                const int sj = sd ? slot[1][j] : slot[0][j];
+                const int sj = cl ? slot[1][j] : slot[0][j];
                 for (int i = tid; i < QB1; i += QT1) {
                     const unsigned v = h[sd * NB + sj * QB1 + i];
                     if (v) atomicAdd(&g[j * QB1 + i], v);
                 }
             }
-            if (LEVEL == 2 && tid < NQ && sh_min[sd * QMAX + tid] != QNONE)
-                atomicMax(&jobs.above[rt[sd] * QMAX + tid], ~sh_min[sd * QMAX + tid]);
+            if (LEVEL == 2 && tid < NQ) {
+                const int sj = cl ? slot[1][tid] : slot[0][tid];      // a duplicate shares the first one's "smallest key above"
+                const unsigned m = sh_min[sd * QMAX + sj];
+                if (m != QNONE) atomicMax(&jobs.above[rt[sd] * QMAX + tid], ~m);
+            }
         }
     }
 }
@@ -647,22 +741,6 @@ __device__ __forceinline__ void qrow_body(const QuantArgs& a, int r, const QRowS
         }
         const float d = v_hi - v_lo;                         // at::lerp: w < 0.5 ? a + w*(b-a) : b - (b-a)*(1-w)
         a.out[(int64_t)j * a.R + r] = (w < 0.5f) ? v_lo + w * d : v_hi - d * (1.f - w);
-    }
-}
-
-// Histogram adds of FOUR consecutive elements per lane (one 16-byte load) for a converged 64-lane wavefront.  The logits of
-// a young encoder lie in a band a few float bins wide, where 256 adds to one LDS address serialise: if every element of
-// every lane is wanted and has the same bin, lane 0 adds 256 at once (one readfirstlane + compares + one ballot per
-// four elements); otherwise the lanes add for themselves.
-__device__ __forceinline__ void hist_add4_wave(unsigned* h, const unsigned (&bin)[4], const bool (&pred)[4]) {
-    const unsigned b0 = (unsigned)__builtin_amdgcn_readfirstlane((int)bin[0]);
-    const bool uni = pred[0] && pred[1] && pred[2] && pred[3] && bin[0] == b0 && bin[1] == b0 && bin[2] == b0 && bin[3] == b0;
-    if (__ballot(!uni) == 0ull) {
-        if ((threadIdx.x & 63) == 0) atomicAdd(&h[b0], 256u);
-    } else {
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (pred[u]) atomicAdd(&h[bin[u]], 1u);
     }
 }
 
@@ -1002,7 +1080,7 @@ static int quant_launch(QuantJobs& jobs, int njobs, void* workspace, int64_t wor
         QuantArgs& a = jobs.job[j];
         int rc = quant_check(a);
         if (rc) return rc;
-        a.chunks = cp2_cdiv(a.N, QCHUNK);
+        a.chunks = cp2_cdiv(cp2_cdiv(a.N, QCHUNK), QCPW);  // chunk WORKGROUPS per row
         jobs.first_row[j] = rows;
         jobs.first_chunk[j] = chunks;
         rows += a.R;

@@ -41,6 +41,8 @@ def step_shape(B, K, P, iters, centre, spread, check=True):
 
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+if len(sys.argv) > 2:                 # one distribution only (for a profiler run): python tools/bench_quantiles.py 8 tight
+    DISTS = tuple(d for d in DISTS if d[0] == sys.argv[2])
 print(f"{'shape':34s} " + " ".join(f"{n:>12s}" for n, _, _ in DISTS) + "   (us per call, hipEvents around back-to-back calls)")
 for label, B, K, P, it in (("cfg2 step: 32x65536 + 2x32x196^2", 32, 65536, 196, iters), ("cfg4 step: 8x131072 + 2x8x4096^2", 8, 131072, 4096, max(3, iters // 4))):
     row = [step_shape(B, K, P, it, c, s_, check=K <= 65536) for _, c, s_ in DISTS]
