@@ -77,11 +77,11 @@ def parse():
     p.add_argument("--flat-sgd", default="on", choices=["on", "off"],
                    help="optimizer step as one HIP launch on the flat parameter buffer (off: torch.optim.SGD) (A/B)")
     p.add_argument("--fused-bn", default="on", choices=["on", "off"], help="encoder fast path: fused BN(+add)(+ReLU) kernels (A/B)")
-    p.add_argument("--overlap", default="auto", choices=["auto", "gather", "on", "off"],
+    p.add_argument("--overlap", default="auto", choices=["auto", "gather", "off"],
                    help="side HIP stream for the key branch: off = everything in order on one stream, gather = EMA + shuffle "
-                        "exchange + key gather on a side stream (north_star's form), on = the key encoder too; auto = one stream at "
-                        "N = 1, and at N > 1 MEASURED: a few steps of each of off / gather after the warm-up, the faster one (max over "
-                        "ranks) runs the timed region and both numbers go into `comm`")
+                        "exchange + key gather on a side stream (north_star's form); auto = one stream at N = 1, and at N > 1 "
+                        "MEASURED: a few steps of each of off / gather after the warm-up, the faster one (max over ranks) runs the "
+                        "timed region and both numbers go into `comm`")
     p.add_argument("--calib-steps", type=int, default=6, help="--overlap auto at N > 1: steps per candidate (>= 5)")
     p.add_argument("--timeout", type=float, default=120.0, help="process-group timeout in seconds (N > 1); the hang watchdog "
                    "names the exchange step that did not complete at 0.8 x this and exits non-zero")
@@ -303,7 +303,7 @@ def main():
     # the EMA is hoisted in front of the rest of the step so each of its launches can be bracketed by HIP events on the
     # launch stream; it reads theta_q after the previous optimizer step and runs before the key encoder, exactly where
     # the reference's call does (builder.py:1272).
-    model.overlap_key_branch = {"auto": None, "gather": "gather", "on": True, "off": False}[args.overlap]
+    model.overlap_key_branch = {"auto": None, "gather": "gather", "off": False}[args.overlap]
     model.ema_in_forward = False
     ema_events = []
 
@@ -403,7 +403,7 @@ def main():
             "backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(), "one_device_rehearsal": bool(args.one_device),
             "single_rank_rehearsal": bool(rehearse),
             "launcher": os.environ.get("CP2_BENCH_LAUNCHER", "external"), "shuffle_exchange": args.shuffle_exchange,
-            "overlap_key_branch": args.overlap, "overlap_used": {None: "off", False: "off", "gather": "gather", True: "on"}[model.overlap_key_branch],
+            "overlap_key_branch": args.overlap, "overlap_used": "gather" if model.overlap_key_branch == "gather" else "off",
             "overlap_calibration": calib, "per_rank": per_rank, "timeout_s": args.timeout, "grad_sync": args.grad_sync,
             "ddp_bucket_mb": args.bucket_mb or builder.DDP_BUCKET_MB,
             "grad_buckets": len(wrapped.reducer.buckets) if args.grad_sync == "flat" else None,

@@ -113,16 +113,20 @@ class DenseCLNeck(nn.Module):
                 "x_avgpool_local_proj": self.avgpool_local(l_proj).flatten(1)}
 
 
-STATS_CHUNK_BYTES = 128 << 20     # raw-logit buffer of the rows-vs-queue score statistics (rank 0, logging): see _queue_infonce_chunked
+# Raw-logit buffer of the rows-vs-queue score statistics (logging): see _queue_infonce_chunked.  Eight samples of 196 pixels
+# against 65536 keys (411 MB) per group at the DenseCL shapes: groups of two samples (103 MB, cache-resident) were measured
+# first and lost -- the loss kernel on 392 rows runs at a third of its 6272-row rate and a 392-workgroup radix select leaves
+# half the chip idle: 16 x (105 + 120) us against 0.6 + 0.5 ms for the whole batch (bench.py --workload cfg5, round 4).
+STATS_CHUNK_BYTES = 448 << 20
 
 
-def _queue_infonce_chunked(rows, ext, queue, temperature, layout, R, need):
-    """rows-vs-queue InfoNCE WITH the per-row score statistics for row counts whose raw logits do not fit a cache-sized
-    buffer (DenseCL local loss on rank 0: 6272 x 65536 fp32 = 1.64 GB, which the reference materialises and sorts,
-    builder.py:871-886).  The rows are walked in groups of whole samples: each group's loss / gradient launch writes its
-    raw logits into ONE re-used buffer of at most STATS_CHUNK_BYTES (it stays in the 256 MB Infinity Cache), the radix-select
-    launch behind it reads them back -- same kernels, same per-row results, bit for bit, as the one-shot form; the queue's
-    bf16 split is made once.  Returns (loss, drows, dE, neg_mean [R], neg_quartiles [3,R])."""
+def _queue_infonce_chunked(rows, ext, queue, temperature, layout, R, need, total_rows=None):
+    """rows-vs-queue InfoNCE WITH the per-row score statistics for row counts whose raw logits should not all exist at once
+    (DenseCL local loss: 6272 x 65536 fp32 = 1.64 GB, which the reference materialises and sorts, builder.py:871-886).  The
+    rows are walked in groups of whole samples: each group's loss / gradient launch writes its raw logits into ONE re-used
+    buffer of at most STATS_CHUNK_BYTES, the radix-select launch behind it reads them back -- same kernels, same per-row
+    results, bit for bit, as the one-shot form; the queue's bf16 split is made once.  `need` None: statistics only (no loss
+    outputs wanted: forward-only launches).  Returns (loss, drows, dE, neg_mean [R], neg_quartiles [3,R])."""
     C, K = queue.shape
     per = max(1, STATS_CHUNK_BYTES // (4 * K))
     if rows.dim() == 3:
@@ -138,7 +142,7 @@ def _queue_infonce_chunked(rows, ext, queue, temperature, layout, R, need):
     row_form = K <= ops.QUANTILES_ROW_MAX
     loss_rows, dE, quart = [], [], []
     ksplit = None
-    precision = "bf16x3" if R >= 1024 else "f32"        # what "auto" picks for the whole call (a group alone may fall below)
+    precision = "bf16x3" if (total_rows or R) >= 1024 else "f32"     # what "auto" picks for the whole batch (a group alone may fall below)
     for a0, a1, rp in spans:
         r0, Rc = a0 * rp, (a1 - a0) * rp
         res = ops.rowkey_infonce(rows[a0:a1], layout, Rc, queue, ext[r0:r0 + Rc], temperature,
@@ -155,6 +159,46 @@ def _queue_infonce_chunked(rows, ext, queue, temperature, layout, R, need):
         if not row_form:
             mean_out.copy_(res.lneg.mean(1))
     return torch.cat(loss_rows).mean(), drows, (torch.cat(dE) if need else None), neg_mean, torch.cat(quart, dim=1)
+
+
+@torch.no_grad()
+def row_score_stats_over_ranks(rows: torch.Tensor, queue: torch.Tensor, src: int = 0) -> torch.Tensor:
+    """[mean, lower, median, upper] over rank `src`'s rows of each row's mean / quartiles of its raw queue logits (the DenseCL
+    score statistics the reference computes on rank 0 alone, builder.py:875-886: a torch.quantile over all 411 M logits,
+    every step, while the other ranks wait for rank 0 at the first gradient bucket).  Here rank `src` broadcasts its rows
+    (b x 128 x S^2 floats: 3.2 MB), every rank takes the statistics of an equal share of them against its own replica of the
+    queue (identical on every rank), and one all-reduce of four sums brings them together: 1/W of the work per rank, nobody
+    a straggler.  Per-row quartiles are the same kernels' results as on one rank (bit for bit); the mean over the rows is
+    summed in another order.  rows: [b,C,S2] (every rank passes its own; only rank `src`'s are used)."""
+    import torch.distributed as tdist
+    b, C, S2 = rows.shape
+    K = queue.shape[1]
+    w, r = cdist.world_size(), cdist.rank()
+    src_rows = rows.detach().float().contiguous()
+    if w > 1:
+        if r != src:
+            src_rows = torch.empty_like(src_rows)
+        cdist.COLLECTIVES.note("score statistics: broadcast of rank 0's rows", tdist.broadcast(src_rows, src, async_op=True)).wait()
+    n0, n1 = (b * r) // w, (b * (r + 1)) // w
+    sums = torch.zeros(4, dtype=torch.float32, device=rows.device)
+    if n1 > n0:
+        part = src_rows[n0:n1]
+        R = (n1 - n0) * S2
+        ext = torch.zeros((R, 1), dtype=torch.float32, device=rows.device)
+        layout = (S2, C * S2, 1, S2)
+        if R * K * 4 > STATS_CHUNK_BYTES:
+            _, _, _, neg_mean, quart = _queue_infonce_chunked(part, ext, queue, 1.0, layout, R, False, total_rows=b * S2)
+        else:
+            res = ops.rowkey_infonce(part, layout, R, queue, ext, 1.0, grad_scale=None, want_lneg=True, lneg_row_major=True,
+                                     precision="bf16x3" if b * S2 >= 1024 else "f32")
+            row_form = K <= ops.QUANTILES_ROW_MAX
+            neg_mean = torch.empty(R, dtype=torch.float32, device=rows.device) if row_form else res.lneg.mean(1)
+            quart = ops.masked_quantiles_multi([dict(x=res.lneg, stride_row=K, stride_elem=1, R=R, N=K,
+                                                     mean_out=neg_mean if row_form else None)])[0]
+        sums = torch.cat([neg_mean.sum().reshape(1), quart.sum(1)])
+    if w > 1:
+        cdist.COLLECTIVES.note("score statistics: all-reduce of the four sums", tdist.all_reduce(sums, async_op=True)).wait()
+    return sums / float(b * S2)
 
 
 class _QueueInfoNCEFn(torch.autograd.Function):
@@ -405,10 +449,10 @@ class MODEL(nn.Module):
         self._flat_q_bf16 = None         # bf16 image of the query weights, written by optim.FlatSGD (enable_query_shadow)
         self._q_shadow_version = None
         self.ema_in_forward = True       # False: the caller runs _momentum_update_key_encoder() itself before forward
-        self.overlap_key_branch = None   # None / False: one stream (default); "gather" / True: side-stream forms, see forward_cp2
+        self.overlap_key_branch = None   # None / False: one stream (default); "gather": the exchange steps on a side stream, see forward_cp2
         self._side_stream = None
         self.key_forward_graph = True    # replay the (gradient-free) key encoder forward from a hipGraph after warm-up
-        self._key_graph = None
+        self._key_graphs = {}
         self._pending_logs = []          # device scalars waiting for one batched device->host copy
         self.shuffle_exchange = "all_to_all"   # shuffle-BN rows by all-to-all; "all_gather" = the reference's form
         self.comm_events = None          # bench.py: {} -> every exchange step records a (start, stop) event pair
@@ -504,9 +548,16 @@ class MODEL(nn.Module):
     def _encode_key(self, img):
         """Key encoder forward (reference builder.py:1276).  No autograd, fixed shapes, static weights addresses
         (the flat buffers): replayed from a hipGraph (engine.ForwardGraph) so its ~280 launches cost no host time."""
+        return self._key_forward("cp2", lambda x: self._encode(self.encoder_k, x), img)
+
+    def _key_forward(self, name, fn, img):
+        """fn(img) -- a gradient-free forward through (parts of) the key encoder returning a tensor or a tuple of tensors --
+        replayed from a hipGraph after three eager calls.  One graph per `name` (the DenseCL step has two key passes whose
+        outputs must both stay alive: "densecl0", "densecl1")."""
         if not self.key_forward_graph or not img.is_cuda:
-            return self._encode(self.encoder_k, img)
-        if self._key_graph is None:
+            return fn(img)
+        graphs = self._key_graphs
+        if name not in graphs:
             from .encoder import FusedBatchNorm2d
             from .engine import ForwardGraph
             bns = [m for m in self.encoder_k.modules() if isinstance(m, FusedBatchNorm2d)]
@@ -515,7 +566,7 @@ class MODEL(nn.Module):
                 # a captured call does not execute: take back the lazy num_batches_tracked ticks it made
                 capturing = torch.cuda.is_current_stream_capturing()
                 before = [m._pending_batches for m in bns] if capturing else None
-                out = self._encode(self.encoder_k, x)
+                out = fn(x)
                 if capturing:
                     fwd.fused = [m for m, b in zip(bns, before) if m._pending_batches != b]
                     for m, b in zip(bns, before):
@@ -528,10 +579,15 @@ class MODEL(nn.Module):
                 for m in fwd.fused:
                     m._pending_batches += 1
 
-            self._key_graph = ForwardGraph(fwd, warmup=3, on_replay=tick)
+            graphs[name] = ForwardGraph(fwd, warmup=3, on_replay=tick)
         # the graph reads the key weights where flatten_parameters() put them: a new home invalidates it
-        return self._key_graph(img, tag=(self._flat_k.data_ptr() if self._flat_k is not None else None,
-                                         self.encoder_k.training, torch.is_grad_enabled()))
+        return graphs[name](img, tag=(self._flat_k.data_ptr() if self._flat_k is not None else None,
+                                      self.encoder_k.training, torch.is_grad_enabled()))
+
+    @property
+    def _key_graph(self):
+        """The CP2 key-forward graph (None before its first use): what the tests and tools inspect."""
+        return self._key_graphs.get("cp2")
 
     def _key_stream(self):
         if self._side_stream is None:
@@ -713,18 +769,21 @@ class MODEL(nn.Module):
 
         # The key branch (EMA -> shuffle-BN exchange -> key encoder -> un-shuffle) does not depend on the query encoder
         # (reference order builder.py:1260-1277 is serial).  overlap_key_branch:
-        #   False / None (default at every world size): everything in order on ONE stream.  Measured with the step's
-        #            collectives running over RCCL with one rank (bench.py --rehearse-collectives): 13.73 ms per step in
-        #            order against 15.1-15.6 ms with "gather" -- a fork / join between HIP streams costs this stack far more
-        #            than the ~0.14 ms of EMA + exchange it can hide;
+        #   False / None (default): everything in order on ONE stream.  Measured with the step's collectives running over
+        #            RCCL with one rank (bench.py --rehearse-collectives): 13.73 ms per step in order against 15.1-15.6 ms with
+        #            "gather" -- a fork / join between HIP streams costs this stack far more than the ~0.14 ms of EMA +
+        #            exchange it can hide when no byte moves; with real peers bench.py --overlap auto
+        #            times both forms and takes the faster;
         #   "gather": EMA + the image exchange (and the key all-gather + enqueue) on a side HIP stream, overlapping the query
-        #            forward; the key encoder itself follows on the main stream;
-        #   True: the whole key branch on the side stream (two compute-heavy branches interleaved on one GPU: 4 % slower
-        #            still, round 1).
+        #            forward (north_star's form); the key encoder itself follows on the main stream.
+        # (The whole key branch on the side stream -- two compute-heavy branches interleaved on one GPU -- measured 4 % slower
+        # in round 1 and 1.3 ms slower in round 3; that form was removed in round 4.)
         self.flatten_parameters()        # on the main stream, before the fork: it re-homes the query parameters too
         self._refresh_query_shadow()
         cur = torch.cuda.current_stream()
         mode = self.overlap_key_branch or False
+        if mode not in (False, "gather"):
+            raise ValueError(f"overlap_key_branch = {self.overlap_key_branch!r}: None / False (one stream) or 'gather'")
         side = self._key_stream() if mode else cur
         if side is not cur:
             side.wait_stream(cur)
@@ -757,7 +816,7 @@ class MODEL(nn.Module):
             if side is not cur and img_b.is_cuda:
                 img_b.record_stream(side)
             img_k, ctx = exchange_in(img_b)
-            if mode != "gather":
+            if not mode:
                 k, k_row = exchange_out(self._encode_key(img_k), ctx)
         q = self._encode(self.encoder_q, img_a).float()                          # queries: b x C x h x w
         if side is not cur:
@@ -802,6 +861,8 @@ class MODEL(nn.Module):
             # builder.py:818-821), and a positive factor per query pixel cannot change an arg-max -- no normalised copy
             return feat.detach(), F.normalize(local.flatten(2), dim=1), F.normalize(glob, dim=1)
 
+        key_pass = [0]
+
         @torch.no_grad()
         def key_features(img):
             """-> (backbone map, local, global, pooled local, k_row): the two maps stay in the key encoder's (shuffled) row
@@ -809,11 +870,17 @@ class MODEL(nn.Module):
             if self.ema_in_forward:
                 self._momentum_update_key_encoder()
             img, ctx = self._batch_shuffle_ddp(img, idx_shuffle)
-            feat = self._encode(self.encoder_k.backbone, img)[3]
-            out = self.encoder_k.neck(feat.float())
-            glob = out["x_avgpool_local_proj"] if self.use_avgpool_global else out["x_global_proj"]
-            local = F.normalize(out["x_local_proj"].flatten(2), dim=1)
-            glob, pooled = F.normalize(glob, dim=1), F.normalize(out["x_avgpool_local_proj"], dim=1)
+
+            def run(x):
+                feat = self._encode(self.encoder_k.backbone, x)[3]
+                out = self.encoder_k.neck(feat.float())
+                glob = out["x_avgpool_local_proj"] if self.use_avgpool_global else out["x_global_proj"]
+                return (feat, F.normalize(out["x_local_proj"].flatten(2), dim=1), F.normalize(glob, dim=1),
+                        F.normalize(out["x_avgpool_local_proj"], dim=1))
+            # backbone + neck of the key side as one hipGraph replay per pass (the eager form costs ~2.5 ms of host time per
+            # step: cfg5 measured host-bound at 17.1 ms); the two passes of the symmetric loss keep separate output buffers
+            feat, local, glob, pooled = self._key_forward(f"densecl{key_pass[0]}", run, img)
+            key_pass[0] += 1
             (feat, local, glob, pooled), k_row = self._key_rows((feat, local, glob, pooled), ctx)
             if k_row is not None:
                 glob, pooled = glob.index_select(0, k_row), pooled.index_select(0, k_row)
@@ -821,6 +888,9 @@ class MODEL(nn.Module):
 
         # rank 0 logs the score statistics of the FIRST pass (reference builder.py:774-804, 875-904: log_metrics=True there only)
         extra = {} if (self.rank == 0 and self.log_quartiles) else None
+        # with peers, the per-pixel score statistics (6272 x 65536 logits) are shared out over the ranks instead of making
+        # rank 0 the straggler every step: row_score_stats_over_ranks (a collective: every rank takes part)
+        share_stats = self.log_quartiles and cdist.multi() and cdist.world_size() > 1
 
         def global_loss(qg, kg, log=False):
             st = {} if (log and extra is not None) else None
@@ -840,12 +910,14 @@ class MODEL(nn.Module):
             st = {} if (log and extra is not None) else None
             pos, _ = densecl_local_positives(q_embed, k_embed, q_local, k_local, ids_q, ids_k, self.lmbd_coordinate, metrics=st,
                                              k_row=k_row, normalize_k=True)
-            loss = queue_infonce(q_local, pos.reshape(-1), self.queue2, self.temp_local, stats=st)
+            loss = queue_infonce(q_local, pos.reshape(-1), self.queue2, self.temp_local,
+                                 stats=st if not share_stats else None)
+            shared = row_score_stats_over_ranks(q_local, self.queue2) if (log and share_stats) else None
             if st is not None:
-                nq = st["neg_quartiles"].mean(1)
+                neg_mean, nq = (shared[0], shared[1:]) if shared is not None else (st["neg_mean"].mean(), st["neg_quartiles"].mean(1))
                 iou, _ = ops.corr_iou(ids_q, ids_k)
                 extra.update({"step/dense_average_positive_scores": pos.detach().mean(),
-                              "step/dense_average_negative_scores": st["neg_mean"].mean(),
+                              "step/dense_average_negative_scores": neg_mean,
                               "step/dense_lower_negative_scores": nq[0], "step/dense_median_negative_scores": nq[1],
                               "step/dense_upper_negative_scores": nq[2], "step/average_iou": iou.mean(),
                               "step/non_zero_iou_ratio": (iou != 0).float().mean(),

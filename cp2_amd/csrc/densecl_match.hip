@@ -29,6 +29,7 @@ constexpr int DM_PB = DM_CKB + 8;   // LDS row pitch in bf16 (36 dwords: the 16 
 constexpr int DM_CKF = 32;    // channels per staged chunk, fp32 path
 constexpr int DM_PQ = DM_X + 1, DM_PK = DM_Y + 1;   // fp32 tiles are channel-major [c][pixel], odd pitch
 constexpr int DM_MAXP = 4096; // key pixels per sample (the id list lives in LDS)
+constexpr int DM_ML = 8;      // id matches per query pixel kept in the LDS list (more: that pixel re-scans the key ids itself)
 
 struct MatchArgs {
     const void* qe; const void* ke;                  // backbone features, element (n, c, p) at n*sn + c*sc + p*sp
@@ -53,6 +54,7 @@ struct DmLds {
     float red[2][8 * DM_X];
     int first[DM_X];
     int cnt[2];
+    int nm[DM_X]; int ml[DM_X * DM_ML];              // per query pixel: number of id-matching key pixels and the first DM_ML of them
     int64_t idk[DM_MAXP];
 };
 
@@ -99,7 +101,7 @@ __device__ __forceinline__ void dm_merge(DmLds& L, float bv, int by, int tid, in
 // Staging: thread t handles elements e = t + 256 i of a [32 channels] x [pixels] chunk; with the channel index fastest
 // in memory e = pixel * 32 + channel, else e = channel * pixels + pixel -- consecutive lanes read consecutive addresses
 // either way, and both are a fixed start plus i times a fixed step.
-__device__ void dm_argmax_f32(DmLds& L, const float* __restrict__ q, int64_t q_sc, int64_t q_sp,
+__device__ __forceinline__ void dm_argmax_f32(DmLds& L, const float* __restrict__ q, int64_t q_sc, int64_t q_sp,
                                                         const float* __restrict__ k, int64_t k_sc, int64_t k_sp, int C, int P, int x0,
                                                         bool normalize, int tid, int* __restrict__ out) {
     const int lane = tid & 63, wid = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -120,7 +122,7 @@ __device__ void dm_argmax_f32(DmLds& L, const float* __restrict__ q, int64_t q_s
     for (int y_base = 0; y_base < P; y_base += DM_Y) {
         f32x16 acc[2] = {{0}, {0}};
         float nsq = 0.f;
-        auto load = [&](int c0) {
+        auto load = [&](int c0) __attribute__((always_inline)) {
             const float* pq = q + (int64_t)(c0 + qc0) * q_sc + (int64_t)(x0 + qx0) * q_sp;
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
@@ -166,42 +168,45 @@ __device__ void dm_argmax_f32(DmLds& L, const float* __restrict__ q, int64_t q_s
     dm_merge(L, bv, by, tid, out);
 }
 
-// ---- bf16 operands, channels-last (sc == 1), C % 64 == 0, 16-byte aligned rows
-__device__ void dm_argmax_bf16(DmLds& L, const unsigned short* __restrict__ q, int64_t q_sp, const unsigned short* __restrict__ k,
+// ---- bf16 operands, channels-last (sc == 1), C % 64 == 0, 16-byte aligned rows.
+// The chunk loop is latency-bound unless the loads run well ahead (8 MFMAs = 256 cycles of work per chunk and wave against
+// an L2 round trip of ~1 us under load: 47 us per launch with the next chunk's loads issued one chunk ahead): two register
+// sets, the loads of chunk c + 2 are issued as soon as chunk c has been stored to LDS.
+struct DmRegs { dm_u32x4 q; dm_u32x4 k[8]; };
+
+__device__ __forceinline__ void dm_argmax_bf16(DmLds& L, const unsigned short* __restrict__ q, int64_t q_sp, const unsigned short* __restrict__ k,
                                int64_t k_sp, int C, int P, int x0, bool normalize, int tid, int* __restrict__ out) {
     const int lane = tid & 63, wid = tid >> 6, r = lane & 31, h = lane >> 5;
     const int row = tid >> 3, seg = tid & 7;      // staging: 8 lanes x 16 B = one pixel's 64-channel chunk
     float bv = -INFINITY; int by = 0;
-    dm_u32x4 rq, rk[8];
     const dm_u32x4 zero = {0, 0, 0, 0};
     for (int y_base = 0; y_base < P; y_base += DM_Y) {
         f32x16 acc[2] = {{0}, {0}};
         float nsq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        auto load = [&](int c0) {
-            rq = (x0 + row < P) ? *reinterpret_cast<const dm_u32x4*>(q + (int64_t)(x0 + row) * q_sp + c0 + seg * 8) : zero;
+        auto load = [&](DmRegs& rg, int c0) __attribute__((always_inline)) {
+            rg.q = (x0 + row < P) ? *reinterpret_cast<const dm_u32x4*>(q + (int64_t)(x0 + row) * q_sp + c0 + seg * 8) : zero;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int y = y_base + row + 32 * i;
-                rk[i] = (y < P) ? *reinterpret_cast<const dm_u32x4*>(k + (int64_t)y * k_sp + c0 + seg * 8) : zero;
+                rg.k[i] = (y < P) ? *reinterpret_cast<const dm_u32x4*>(k + (int64_t)y * k_sp + c0 + seg * 8) : zero;
             }
         };
-        load(0);
-        for (int c0 = 0; c0 < C; c0 += DM_CKB) {
-            __syncthreads();
-            *reinterpret_cast<dm_u32x4*>(L.t.b.q + row * DM_PB + seg * 8) = rq;
+        auto stage = [&](DmRegs& rg, int c0) __attribute__((always_inline)) {       // registers -> LDS (+ key norms), refill the set two chunks ahead, multiply
+            __syncthreads();                         // the previous chunk's MFMAs have read the tiles
+            *reinterpret_cast<dm_u32x4*>(L.t.b.q + row * DM_PB + seg * 8) = rg.q;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                *reinterpret_cast<dm_u32x4*>(L.t.b.k + (row + 32 * i) * DM_PB + seg * 8) = rk[i];
+                *reinterpret_cast<dm_u32x4*>(L.t.b.k + (row + 32 * i) * DM_PB + seg * 8) = rg.k[i];
                 if (normalize) {
 #pragma unroll
                     for (int w = 0; w < 4; ++w) {
-                        const float lo = __uint_as_float(rk[i][w] << 16), hi = __uint_as_float(rk[i][w] & 0xFFFF0000u);
+                        const float lo = __uint_as_float(rg.k[i][w] << 16), hi = __uint_as_float(rg.k[i][w] & 0xFFFF0000u);
                         nsq[i] = fmaf(lo, lo, nsq[i]);
                         nsq[i] = fmaf(hi, hi, nsq[i]);
                     }
                 }
             }
-            if (c0 + DM_CKB < C) load(c0 + DM_CKB);
+            if (c0 + 2 * DM_CKB < C) load(rg, c0 + 2 * DM_CKB);
             __syncthreads();
             if (y_base + 64 * wid < P) {
                 const __bf16* pq = L.t.b.q + r * DM_PB + 8 * h;
@@ -215,6 +220,13 @@ __device__ void dm_argmax_bf16(DmLds& L, const unsigned short* __restrict__ q, i
                     acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b, acc[1], 0, 0, 0);
                 }
             }
+        };
+        DmRegs ra, rb;
+        load(ra, 0);
+        if (DM_CKB < C) load(rb, DM_CKB);
+        for (int c0 = 0; c0 < C; c0 += 2 * DM_CKB) {
+            stage(ra, c0);
+            if (c0 + DM_CKB < C) stage(rb, c0 + DM_CKB);
         }
         __syncthreads();
         if (normalize) {
@@ -231,10 +243,10 @@ __device__ void dm_argmax_bf16(DmLds& L, const unsigned short* __restrict__ q, i
     dm_merge(L, bv, by, tid, out);
 }
 
-// METRICS instantiations carry the second (fp32) arg-max routine.  Launch bound: 256 registers, so that
-// two workgroups share a CU (LDS: 2 x 78 KB)
+// METRICS instantiations carry the second (fp32) arg-max routine.  One workgroup per CU (B x ceil(P / 32) work items: 224 at
+// 32 x 196 pixels, fewer than the chip has CUs): the register budget goes to the two load sets in flight, not to occupancy.
 template <bool BF, bool METRICS>
-__global__ __launch_bounds__(256, 2) void densecl_match_kernel(MatchArgs a) {
+__global__ __launch_bounds__(256) void densecl_match_kernel(MatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dm_smem[];
     DmLds& L = *reinterpret_cast<DmLds*>(dm_smem);
     const int tid = threadIdx.x;
@@ -277,10 +289,33 @@ __global__ __launch_bounds__(256, 2) void densecl_match_kernel(MatchArgs a) {
         pos_part = fmaf(qv[i], kb[i], pos_part);
         S[i] = 0.f;
     }
-    if (scan && x_ok) {
-        const int64_t idq = a.ids_q[(int64_t)n * P + x];
-        for (int y = 0; y < P; ++y) {
-            if (L.idk[y] != idq) continue;
+    if (scan) {
+        // the eight threads of a query pixel share the search for key pixels with its id (an eighth of the key map each),
+        // collect them in a short LDS list, and one of them puts the list in y order (the sums below must not depend on
+        // which thread found a match first)
+        if (tid < DM_X) L.nm[tid] = 0;
+        __syncthreads();
+        const int64_t idq = x_ok ? a.ids_q[(int64_t)n * P + x] : 0;
+        const int per = (P + 7) / 8;
+        if (x_ok)
+            for (int y = g * per; y < min(P, (g + 1) * per); ++y)
+                if (L.idk[y] == idq) {
+                    const int at = atomicAdd(&L.nm[xl], 1);
+                    if (at < DM_ML) L.ml[xl * DM_ML + at] = y;
+                }
+        __syncthreads();
+        const int nm = L.nm[xl];
+        if (g == 0 && nm > 1 && nm <= DM_ML) {
+            int* lst = L.ml + xl * DM_ML;
+            for (int i = 1; i < nm; ++i) {
+                const int v = lst[i];
+                int j = i - 1;
+                for (; j >= 0 && lst[j] > v; --j) lst[j + 1] = lst[j];
+                lst[j + 1] = v;
+            }
+        }
+        __syncthreads();
+        auto take = [&](int y) __attribute__((always_inline)) {
             first = min(first, y);
             float d = 0.f;
 #pragma unroll
@@ -290,6 +325,12 @@ __global__ __launch_bounds__(256, 2) void densecl_match_kernel(MatchArgs a) {
                 S[i] += kv;
             }
             coord_part += d;          // builder.py:846-848: sum over the matching key pixels, in y order
+        };
+        if (x_ok && nm <= DM_ML) {
+            for (int m = 0; m < nm; ++m) take(L.ml[xl * DM_ML + m]);
+        } else if (x_ok) {            // an id repeated more than DM_ML times among the keys: this pixel walks the whole list
+            for (int y = 0; y < P; ++y)
+                if (L.idk[y] == idq) take(y);
         }
     }
     L.red[0][g * DM_X + xl] = pos_part;

@@ -257,50 +257,14 @@ __global__ __launch_bounds__(256, WK == 1 ? 2 : 1) void rowkey_fwd_kernel(RowKey
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Split-bf16 variant of rowkey_fwd_kernel<4,1,*> for the MFMA-bound case (thousands of rows, config 5).
-// Every fp32 operand x is used as hi + lo with hi = bf16(x), lo = bf16(x - hi) and every product as
-// hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulate): 3 MFMAs of 32 cycles replace 8 f32 MFMAs of
-// 64 cycles per 32x32x16 block (5.3x fewer matrix-pipe cycles) at <= 3*2^-18 relative error per term, i.e. <= 1.2e-5
-// on logits of unit vectors (the reference bound is 1e-4).  Same orientation, partial-state layout and finalize as
-// the f32 kernel; only the LDS images and the two products differ:
-//   image 1 (product 1: keys x channels)  T1[key][c]  bf16, 272-byte rows -> conflict-free 16-byte A-fragment reads
-//   image 2 (product 2: channels x keys)  T2[c][key]  bf16, 136-byte rows -> conflict-free 8-byte reads; the 8 keys
-//           of a fragment follow the accumulator's row order 16s + 8(j>>2) + 4h + (j&3), so the soft-max
-//           accumulator registers 8s..8s+7 are the B fragment of k-step s with no lane movement.
-// Both images are produced in-kernel from the fp32 [C][K] queue (no extra global state to maintain).
+// Split-bf16 form for the MFMA-bound case (thousands of rows, config 5): rowkey_bf16x3.hip.  Every fp32 operand x is used
+// as hi + lo with hi = bf16(x), lo = bf16(x - hi) and every product as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16
+// (fp32 accumulate): 3 MFMAs of 32 cycles replace 8 f32 MFMAs of 64 cycles per 32x32x16 block at <= 3*2^-18 relative error
+// per term, i.e. <= 1.2e-5 on logits of unit vectors (the reference bound is 1e-4).  Here: the prep kernel of its key operand.
 // ---------------------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x16 mfma_bf(bf16x8 a, bf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-constexpr int BKT = 64;                      // keys per LDS tile
-constexpr int T1P = 272, T2P = 136;          // row pitches in bytes
-constexpr int T1B = BKT * T1P, T2B = CH * T2P;
-constexpr int BF_LDS = 2 * T1B + 2 * T2B;    // T1 hi | T1 lo | T2 hi | T2 lo = 69632 bytes
-
 __device__ __forceinline__ void split_bf(float v, __bf16& hi, __bf16& lo) {
     hi = (__bf16)v;
     lo = (__bf16)(v - (float)hi);
-}
-
-__device__ __forceinline__ void tile_store_bf(unsigned char* __restrict__ sm, const TileRegs<BKT>& rg, int tid) {
-#pragma unroll
-    for (int i = 0; i < CH * BKT / 1024; ++i) {
-        const int e = tid + i * 256, c = e / (BKT / 4), j = (e % (BKT / 4)) * 4;
-        const float v[4] = {rg.v[i].x, rg.v[i].y, rg.v[i].z, rg.v[i].w};
-        bf16x4 h4, l4;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            __bf16 hi, lo;
-            split_bf(v[u], hi, lo);
-            h4[u] = hi; l4[u] = lo;
-            *reinterpret_cast<__bf16*>(sm + (j + u) * T1P + c * 2) = hi;
-            *reinterpret_cast<__bf16*>(sm + T1B + (j + u) * T1P + c * 2) = lo;
-        }
-        *reinterpret_cast<bf16x4*>(sm + 2 * T1B + c * T2P + j * 2) = h4;
-        *reinterpret_cast<bf16x4*>(sm + 2 * T1B + T2B + c * T2P + j * 2) = l4;
-    }
 }
 
 // Pre-split form of the key operand for the bf16x3 kernel: the fp32 queue [C][K] is converted ONCE per call into
@@ -335,178 +299,6 @@ __global__ __launch_bounds__(256) void keys_split_kernel(const float* __restrict
             split_bf(tile[j][c], hi, lo);
             qth[(int64_t)(k0 + j) * CH + c] = hi;
             qtl[(int64_t)(k0 + j) * CH + c] = lo;
-        }
-    }
-}
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-
-// LDS images from the pre-split arrays: 16-byte global loads, ds_write_b128 (image 1) / 2 x ds_write_b64 (image 2).
-__device__ __forceinline__ void tile_fill_presplit(unsigned char* __restrict__ sm, const __bf16* __restrict__ split, int K,
-                                                   int k0, int k_end, int tid) {
-    const int64_t CK = (int64_t)CH * K;
-    u32x4 v1[8], v2[8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {                          // image 1: 64 key rows x 16 chunks, hi then lo
-        const int e = tid + i * 256, key = e >> 4, q = e & 15;
-        const bool ok = k0 + key < k_end;
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        v1[i] = ok ? *reinterpret_cast<const u32x4*>(split + (int64_t)(k0 + key) * CH + q * 8) : z;
-        v1[4 + i] = ok ? *reinterpret_cast<const u32x4*>(split + CK + (int64_t)(k0 + key) * CH + q * 8) : z;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {                          // image 2: 128 channel rows x 8 chunks of 8 keys
-        const int e = tid + i * 256, c = e >> 3, q = e & 7;
-        const bool ok = k0 + q * 8 < k_end;                // K % 8 == 0 and k_end % 8 == 0: a chunk is all-or-nothing
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        v2[i] = ok ? *reinterpret_cast<const u32x4*>(split + 2 * CK + (int64_t)c * K + k0 + q * 8) : z;
-        v2[4 + i] = ok ? *reinterpret_cast<const u32x4*>(split + 3 * CK + (int64_t)c * K + k0 + q * 8) : z;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int e = tid + i * 256, key = e >> 4, q = e & 15;
-        *reinterpret_cast<u32x4*>(sm + key * T1P + q * 16) = v1[i];
-        *reinterpret_cast<u32x4*>(sm + T1B + key * T1P + q * 16) = v1[4 + i];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int e = tid + i * 256, c = e >> 3, q = e & 7;
-        unsigned char* d = sm + 2 * T1B + c * T2P + q * 16;
-        *reinterpret_cast<u32x2*>(d) = (u32x2){v2[i].x, v2[i].y};
-        *reinterpret_cast<u32x2*>(d + 8) = (u32x2){v2[i].z, v2[i].w};
-        *reinterpret_cast<u32x2*>(d + T2B) = (u32x2){v2[4 + i].x, v2[4 + i].y};
-        *reinterpret_cast<u32x2*>(d + T2B + 8) = (u32x2){v2[4 + i].z, v2[4 + i].w};
-    }
-}
-
-template <bool WITH_U, bool PRESPLIT>
-__global__ __launch_bounds__(256, 2) void rowkey_fwd_bf16x3_kernel(RowKeyArgs a, const __bf16* __restrict__ ksplit) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int row = (blockIdx.x * 4 + wid) * 32 + r;
-    const bool row_ok = row < a.R;
-    bf16x8 bqh[CH / 16], bql[CH / 16];
-    {
-        const int rr = row_ok ? row : 0;
-        const float* base = a.rows + (int64_t)(rr / a.RP) * a.r_sn + (int64_t)(rr % a.RP) * a.r_sx;
-#pragma unroll
-        for (int st = 0; st < CH / 16; ++st) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float v = row_ok ? base[(int64_t)(16 * st + 8 * h + j) * a.r_sc] : 0.f;
-                __bf16 hi, lo;
-                split_bf(v, hi, lo);
-                bqh[st][j] = hi; bql[st][j] = lo;
-            }
-        }
-    }
-    const float pos_s = (row_ok && a.NE > 0) ? a.extras[(int64_t)row * a.NE] * a.inv_t : INFINITY;
-    float m_run = -INFINITY, s_run = 0.f;
-    int cnt = 0;
-    f32x16 U[4];
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb) U[cb] = (f32x16){0};
-    const int k_begin = blockIdx.y * a.keys_per_split;
-    const int k_end = min(a.K, k_begin + a.keys_per_split);
-    const bool vec_ok = (a.K % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.keys) & 15u) == 0);
-    TileRegs<BKT> rg;
-    if (!PRESPLIT) tile_load<BKT>(rg, a.keys, a.K, k_begin, k_end, tid, vec_ok);
-    for (int k0 = k_begin; k0 < k_end; k0 += BKT) {
-        __syncthreads();
-        if (PRESPLIT) {
-            tile_fill_presplit(smb, ksplit, a.K, k0, k_end, tid);
-        } else {
-            tile_store_bf(smb, rg, tid);
-        }
-        __syncthreads();
-        if (!PRESPLIT && k0 + BKT < k_end) tile_load<BKT>(rg, a.keys, a.K, k0 + BKT, k_end, tid, vec_ok);
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            const int kk = sub * 32;
-            if (k0 + kk >= k_end) continue;  // wave-uniform
-            f32x16 acc = {0};
-            {
-                const unsigned char* p1 = smb + (kk + r) * T1P + h * 16;
-#pragma unroll
-                for (int st = 0; st < CH / 16; ++st) {
-                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(p1 + st * 32);
-                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(p1 + T1B + st * 32);
-                    acc = mfma_bf(ah, bqh[st], acc);
-                    acc = mfma_bf(ah, bql[st], acc);
-                    acc = mfma_bf(al, bqh[st], acc);
-                }
-            }
-            float sv[16];
-            float tmax = -INFINITY;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int key = k0 + kk + rho(reg, h);
-                const bool valid = key < k_end;
-                if (a.lnegT && valid && row_ok) a.lnegT[(int64_t)key * a.ln_sk + (int64_t)row * a.ln_sr] = acc[reg];
-                sv[reg] = valid ? acc[reg] * a.inv_t : -INFINITY;
-                tmax = fmaxf(tmax, sv[reg]);
-                cnt += (sv[reg] > pos_s) ? 1 : 0;
-            }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            if (__any(tmax > m_run)) {
-                const float m_new = fmaxf(m_run, tmax);
-                const float sc = __expf(m_run - m_new);
-                s_run *= sc;
-                if (WITH_U) {
-#pragma unroll
-                    for (int cb = 0; cb < 4; ++cb) U[cb] *= sc;
-                }
-                m_run = m_new;
-            }
-            float p[16];
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                p[reg] = __expf(sv[reg] - m_run);
-                s_run += p[reg];
-            }
-            if (WITH_U) {
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    bf16x8 ph, pl;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        __bf16 hi, lo;
-                        split_bf(p[8 * ks + j], hi, lo);
-                        ph[j] = hi; pl[j] = lo;
-                    }
-                    const unsigned char* p2 = smb + 2 * T1B + r * T2P + (kk + 16 * ks + 4 * h) * 2;
-#pragma unroll
-                    for (int cb = 0; cb < 4; ++cb) {
-                        const unsigned char* q2 = p2 + cb * 32 * T2P;
-                        const bf16x4 h0 = *reinterpret_cast<const bf16x4*>(q2), h1 = *reinterpret_cast<const bf16x4*>(q2 + 16);
-                        const bf16x4 l0 = *reinterpret_cast<const bf16x4*>(q2 + T2B), l1 = *reinterpret_cast<const bf16x4*>(q2 + T2B + 16);
-                        const bf16x8 ah = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-                        const bf16x8 al = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-                        U[cb] = mfma_bf(ah, ph, U[cb]);
-                        U[cb] = mfma_bf(al, ph, U[cb]);
-                        U[cb] = mfma_bf(ah, pl, U[cb]);
-                    }
-                }
-            }
-        }
-    }
-    const float s_tot = s_run + __shfl_xor(s_run, 32, 64);
-    const int cnt_tot = cnt + __shfl_xor(cnt, 32, 64);
-    const int slot = blockIdx.y;
-    if (row_ok) {
-        if (h == 0) {
-            a.part_m[(int64_t)slot * a.R + row] = m_run;
-            a.part_s[(int64_t)slot * a.R + row] = s_tot;
-            a.part_cnt[(int64_t)slot * a.R + row] = cnt_tot;
-        }
-        if (WITH_U) {
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg)
-                    a.part_U[((int64_t)slot * CH + cb * 32 + rho(reg, h)) * a.R + row] = U[cb][reg];
         }
     }
 }
@@ -698,13 +490,14 @@ CP2_API int cp2_rowkey_infonce_fwd(const float* rows, int RP, int64_t r_sn, int6
     if (NE > 0 && !extras) return CP2_ERR_NULL;
     if (R <= 0 || K <= 0 || RP <= 0 || nsplit <= 0 || NE < 0 || NE > 4 || !(temperature > 0.f)) return CP2_ERR_SHAPE;
     if (C != CH) return CP2_ERR_UNSUPPORTED;
+    if (precision != 0 && precision != 1 && precision != 3) return CP2_ERR_SHAPE;
     const bool split_ready = precision == 3;      // keys_split already holds this queue's split (an earlier call wrote it)
     if (split_ready) precision = 1;
     const int64_t ln_sk = lneg_row_major ? 1 : R, ln_sr = lneg_row_major ? K : 1;
     if (rowkey_use_small(R, K) && rowkey_small_rows_ok(rows, r_sn, r_sx, r_sc, keys)) {
         RowKeyArgs sa{rows, RP, r_sn, r_sx, r_sc, R, keys, K, extras, NE, 1.0f / temperature, 0,
                       part_m, part_s, part_cnt, part_U, lnegT, ln_sk, ln_sr};
-        return rowkey_small_launch(sa, nsplit, part_U != nullptr, precision == 2, cp2_stream(stream));
+        return rowkey_small_launch(sa, nsplit, part_U != nullptr, cp2_stream(stream));
     }
     int WR, WK;
     rowkey_shape(R, &WR, &WK);
@@ -733,11 +526,7 @@ CP2_API int cp2_rowkey_infonce_fwd(const float* rows, int RP, int64_t r_sn, int6
             return rowkey_bf16x3_dma_launch(a, ks, grid, wu, cp2_stream(stream));
         }
         if (split_ready) return CP2_ERR_UNSUPPORTED;   // the caller's split cannot be used for this shape
-        auto kfn = wu ? rowkey_fwd_bf16x3_kernel<true, false> : rowkey_fwd_bf16x3_kernel<false, false>;
-        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, BF_LDS);
-        if (e_ != hipSuccess) return (int)e_;
-        CP2_LAUNCH_PROFILED(kfn, grid, block, BF_LDS, cp2_stream(stream), a, (const __bf16*)nullptr);
-        return cp2_launch_status();
+        // (K % 16 != 0 or no workspace: the exact-fp32 kernel below serves the call)
     }
 #define CP2_LAUNCH_RK(wr_, wk_, wu_)                                                                            \
     do {                                                                                                        \
@@ -941,94 +730,9 @@ __global__ __launch_bounds__(DNT, 2) void dense_fwd_kernel(DenseArgs a) {
     }
 }
 
-// Fold the S partial column statistics of dense_fwd_kernel (one thread per (sample, key pixel)).  Splits cover
-// increasing x ranges, so "first maximum" (torch.argmax's tie rule) = strictly-greater replacement in split order.
-__global__ __launch_bounds__(256) void dense_merge_kernel(DenseArgs a, int64_t BP) {
-    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (o >= BP) return;
-    const int S = a.splits;
-    const int64_t arr = (int64_t)S * BP;
-    const float* q = a.part + o;
-    float M = -INFINITY;
-    for (int sp = 0; sp < S; ++sp) M = fmaxf(M, q[(int64_t)sp * BP]);
-    float s = 0.f, ca = 0.f, pos = 0.f, all = 0.f, bv = -INFINITY;
-    int bx = 0;
-    for (int sp = 0; sp < S; ++sp) {
-        const float* e = q + (int64_t)sp * BP;
-        const float m = e[0];
-        if (m > -INFINITY) s += e[arr] * __expf(m - M);
-        ca += e[2 * arr]; pos += e[3 * arr]; all += e[4 * arr];
-        const float v = e[5 * arr];
-        if (v > bv) { bv = v; bx = __float_as_int(e[6 * arr]); }
-    }
-    a.lse[o] = M + logf(s);
-    a.colsum_a[o] = ca;
-    a.possum[o] = pos;
-    a.allsum[o] = all;
-    a.colmax[o] = bv;
-    a.argx[o] = bx;
-}
-
-// One workgroup per sample: Sa, Sb, the sample's loss, logging means, arg-max label.
-// sample_scal[n] = {Sa, Sb, loss_n, mean positive score, mean negative score, label at arg-max, 0, 0}
-__global__ __launch_bounds__(256) void dense_finalize_kernel(DenseArgs a, float* __restrict__ sample_scal) {
-    __shared__ float red[6][4];
-    __shared__ float bv[4];
-    __shared__ int bi[4];
-    const int n = blockIdx.x, P = a.P, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    float sa = 0.f, sb = 0.f, t_lse = 0.f, t_a = 0.f, t_pos = 0.f, t_all = 0.f, best = -INFINITY;
-    int64_t best_flat = 0;
-    for (int y = tid; y < P; y += 256) {
-        const int64_t o = (int64_t)n * P + y;
-        const float mb = a.mask_b[o];
-        sa += a.mask_a[o];
-        sb += mb;
-        t_lse += mb * a.lse[o];
-        t_a += mb * a.colsum_a[o];
-        t_pos += mb * a.possum[o];
-        t_all += a.allsum[o];
-        const float v = a.colmax[o];
-        const int64_t flat = (int64_t)a.argx[o] * P + y;
-        if (v > best || (v == best && flat < best_flat)) { best = v; best_flat = flat; }
-    }
-    float vals[6] = {sa, sb, t_lse, t_a, t_pos, t_all};
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const float s = wave_sum(vals[j]);
-        if (lane == 0) red[j][w] = s;
-    }
-    // arg-max across the wave, then across waves (ties -> smallest flat index, as torch.argmax)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float ov = __shfl_xor(best, off, 64);
-        const int64_t of = __shfl_xor(best_flat, off, 64);
-        if (ov > best || (ov == best && of < best_flat)) { best = ov; best_flat = of; }
-    }
-    if (lane == 0) { bv[w] = best; bi[w] = (int)best_flat; }
-    __syncthreads();
-    if (tid == 0) {
-        float t[6];
-        for (int j = 0; j < 6; ++j) t[j] = red[j][0] + red[j][1] + red[j][2] + red[j][3];
-        float bb = bv[0];
-        int bf = bi[0];
-        for (int j = 1; j < 4; ++j)
-            if (bv[j] > bb || (bv[j] == bb && bi[j] < bf)) { bb = bv[j]; bf = bi[j]; }
-        const float Sa = t[0], Sb = t[1], npos = Sa * Sb;
-        float* o = sample_scal + (int64_t)n * 8;
-        o[0] = Sa;
-        o[1] = Sb;
-        o[2] = (Sa * t[2] - t[3]) / npos;                 // 0/0 = NaN when a mask is empty, as the reference
-        o[3] = t[4] / npos;
-        o[4] = (t[5] - t[4]) / ((float)P * (float)P - npos);
-        o[5] = a.mask_a[(int64_t)n * P + bf / P] * a.mask_b[(int64_t)n * P + bf % P];
-        o[6] = 0.f;
-        o[7] = 0.f;
-    }
-}
-
-// dense_merge_kernel + dense_finalize_kernel in one launch (round 3): one workgroup per sample folds the S partial column
-// statistics of its own key pixels (same operations, same order as dense_merge_kernel), stores the merged per-key
-// values the backward and the callers read, and finishes the sample's scalars from them.
+// One workgroup per sample folds the S partial column statistics of its own key pixels (splits cover increasing x ranges,
+// so "first maximum" -- torch.argmax's tie rule -- = strictly-greater replacement in split order), stores the merged
+// per-key values the backward and the callers read, and finishes the sample's scalars from them.
 __global__ __launch_bounds__(256) void dense_post_kernel(DenseArgs a, float* __restrict__ sample_scal, int64_t BP) {
     __shared__ float red[6][4];
     __shared__ float bv[4];
@@ -1103,15 +807,6 @@ __global__ __launch_bounds__(256) void dense_post_kernel(DenseArgs a, float* __r
         o[6] = 0.f;
         o[7] = 0.f;
     }
-}
-
-// out[0] = mean_n scal[n][2] (dense loss), out[1] = 100 * mean_n scal[n][5] (arg-max accuracy)
-__global__ __launch_bounds__(64) void dense_batch_kernel(const float* __restrict__ scal, int B, float* __restrict__ out) {
-    float l = 0.f, c = 0.f;
-    for (int n = threadIdx.x; n < B; n += 64) { l += scal[n * 8 + 2]; c += scal[n * 8 + 5]; }
-    l = wave_sum(l);
-    c = wave_sum(c);
-    if (threadIdx.x == 0) { out[0] = l / (float)B; out[1] = 100.f * c / (float)B; }
 }
 
 // owners = query pixels x (lane), others = key pixels y (LDS tile).
@@ -1193,15 +888,6 @@ __global__ __launch_bounds__(DNT, 2) void dense_bwd_kernel(DenseArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void dense_grad_sum_kernel(const float* __restrict__ part, float* __restrict__ g, int S,
-                                                             int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float acc = part[i];
-    for (int sp = 1; sp < S; ++sp) acc += part[(int64_t)sp * n + i];
-    g[i] = acc;
-}
-
 static int dense_check(const float* qd, const float* kd, const float* ma, const float* mb, const int64_t* pa,
                        const int64_t* pb, const int64_t* ra, const int64_t* rb, int B, int C, int P, float t) {
     if (!qd || !kd || !ma || !mb) return CP2_ERR_NULL;
@@ -1228,7 +914,7 @@ CP2_API int cp2_dense_infonce_fwd(const float* q_dense, const float* k_dense, co
                                   const float* mask_b, const int64_t* pix_a, const int64_t* pix_b,
                                   const int64_t* reg_a, const int64_t* reg_b, float w_pixel, float w_region,
                                   float w_not, float temperature, float* lse, float* colsum_a, float* possum,
-                                  float* allsum, float* colmax, int32_t* argx, float* sample_scal, float* batch_out,
+                                  float* allsum, float* colmax, int32_t* argx, float* sample_scal,
                                   float* logits_out, float* split_ws, int negative_mode, float negative_scale,
                                   const float* negative_center, int B, int C, int P, void* stream) {
     int rc = dense_check(q_dense, k_dense, mask_a, mask_b, pix_a, pix_b, reg_a, reg_b, B, C, P, temperature);
@@ -1248,10 +934,7 @@ CP2_API int cp2_dense_infonce_fwd(const float* q_dense, const float* k_dense, co
     rc = cp2_launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(dense_post_kernel, dim3(B), dim3(256), 0, cp2_stream(stream), a, sample_scal, (int64_t)B * P);
-    rc = cp2_launch_status();
-    if (rc || !batch_out) return rc;                       // batch_out NULL: the caller forms the batch means (cp2_step_scalars)
-    hipLaunchKernelGGL(dense_batch_kernel, dim3(1), dim3(64), 0, cp2_stream(stream), sample_scal, B, batch_out);
-    return cp2_launch_status();
+    return cp2_launch_status();                            // the batch means are formed by cp2_step_scalars
 }
 
 CP2_API int cp2_dense_infonce_bwd(const float* q_dense, const float* k_dense, const float* mask_a,
@@ -1265,7 +948,7 @@ CP2_API int cp2_dense_infonce_bwd(const float* q_dense, const float* k_dense, co
     if (rc) return rc;
     if (!lse || !sample_scal) return CP2_ERR_NULL;
     const int S = split_ws ? cp2_dense_num_splits(B, P) : 1;
-    if (!g_dense && S == 1) return CP2_ERR_NULL;           // g_dense NULL: leave the S partial gradients in split_ws (cp2_feat_bwd_fused adds them)
+    if (S == 1 ? !g_dense : g_dense != nullptr) return CP2_ERR_NULL;   // S > 1: the S partial gradients stay in split_ws (cp2_feat_bwd_fused adds them)
     DenseArgs a{q_dense, k_dense, mask_a, mask_b, pix_a, pix_b, reg_a, reg_b, w_pixel, w_region, w_not,
                 1.0f / temperature, P, const_cast<float*>(lse), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                 sample_scal, grad_scale, g_dense, S, split_ws, negative_scale, negative_center};
@@ -1276,10 +959,5 @@ CP2_API int cp2_dense_infonce_bwd(const float* q_dense, const float* k_dense, co
         else CP2_LAUNCH_PROFILED((dense_bwd_kernel<false, true>), grid, dim3(DNT), lds, cp2_stream(stream), a);
     } else if (pix_a) CP2_LAUNCH_PROFILED((dense_bwd_kernel<true, false>), grid, dim3(DNT), lds, cp2_stream(stream), a);
     else CP2_LAUNCH_PROFILED((dense_bwd_kernel<false, false>), grid, dim3(DNT), lds, cp2_stream(stream), a);
-    rc = cp2_launch_status();
-    if (rc || S == 1 || !g_dense) return rc;
-    const int64_t n = (int64_t)B * CH * P;
-    hipLaunchKernelGGL(dense_grad_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cp2_stream(stream), split_ws,
-                       g_dense, S, n);
     return cp2_launch_status();
 }

@@ -32,7 +32,7 @@ struct RowKeyFinArgs {
 
 // Small-R form (R <= 32 rows, K % 4 == 0, 16-byte aligned keys): rowkey_small.hip
 int rowkey_small_num_splits(int K, int* tiles_per_wg);
-int rowkey_small_launch(const RowKeyArgs& a, int nsplit, bool with_u, bool p1_bf16, hipStream_t stream);
+int rowkey_small_launch(const RowKeyArgs& a, int nsplit, bool with_u, hipStream_t stream);
 int rowkey_small_finalize_launch(const RowKeyFinArgs& a, float* loss_mean, hipStream_t stream);
 
 // Many-rows split-bf16 form with LDS-DMA double buffering (rowkey_bf16x3.hip); ksplit = the four arrays keys_split_kernel writes

@@ -93,41 +93,25 @@ __device__ __forceinline__ unsigned block_scan_incl(unsigned v, unsigned* wtot) 
     return incl + base;
 }
 
-// Histogram adds of FOUR consecutive elements per lane (one 16-byte load) for a converged 64-lane wavefront (row kernel).
-// Narrow-band rows put most of a wavefront's 256 elements into one or two bins, and 64 lanes adding to one LDS address
-// serialise.  Probe: lane 0's bin of slot 0 is broadcast and counted over slot 0 (one ballot); a spread-out row fails the
-// probe (fewer than a quarter of the lanes) and every lane adds for itself, as before.  Otherwise
-// the bin is counted over all four slots and ONE lane adds the count (a freshly initialised encoder -- every logit within a
-// few ulps of 1 -- ends here: one add per 256 elements); the same is done once more for the bin of the first element still
-// pending (the positive scores of a trained encoder: two hot first-level bins), and only the stragglers add for themselves.
+// Histogram adds of FOUR consecutive elements per lane (one 16-byte load) for a converged 64-lane wavefront.  The logits of
+// a young encoder lie in a band a few float bins wide, where 256 adds to one LDS address serialise: if every element of
+// every lane is wanted and has the same bin, lane 0 adds 256 at once (one readfirstlane + compares + one ballot per
+// four elements); otherwise the lanes add for themselves.
 __device__ __forceinline__ void hist_add4_wave(unsigned* h, const unsigned (&bin)[4], const bool (&pred)[4]) {
-    const int lane = threadIdx.x & 63;
-    bool pend[4] = {pred[0], pred[1], pred[2], pred[3]};
-    // (lane 0's element stands for "the first wanted one": if it is not wanted the probe merely fails)
     const unsigned b0 = (unsigned)__builtin_amdgcn_readfirstlane((int)bin[0]);
-    if (__popcll(__ballot(pend[0] && bin[0] == b0)) >= 16) {
+    const bool uni = pred[0] && pred[1] && pred[2] && pred[3] && bin[0] == b0 && bin[1] == b0 && bin[2] == b0 && bin[3] == b0;
+    if (__ballot(!uni) == 0ull) {
+        if ((threadIdx.x & 63) == 0) atomicAdd(&h[b0], 256u);
+    } else {
 #pragma unroll
-        for (int round = 0; round < 2; ++round) {
-            const unsigned long long m0 = __ballot(pend[0]), m1 = __ballot(pend[1]), m2 = __ballot(pend[2]), m3 = __ballot(pend[3]);
-            const int total = __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
-            if (total == 0) return;
-            unsigned b;
-            if (m0) b = (unsigned)__builtin_amdgcn_readlane((int)bin[0], __ffsll((long long)m0) - 1);
-            else if (m1) b = (unsigned)__builtin_amdgcn_readlane((int)bin[1], __ffsll((long long)m1) - 1);
-            else if (m2) b = (unsigned)__builtin_amdgcn_readlane((int)bin[2], __ffsll((long long)m2) - 1);
-            else b = (unsigned)__builtin_amdgcn_readlane((int)bin[3], __ffsll((long long)m3) - 1);
-            const bool e0 = pend[0] && bin[0] == b, e1 = pend[1] && bin[1] == b, e2 = pend[2] && bin[2] == b, e3 = pend[3] && bin[3] == b;
-            const int cnt = __popcll(__ballot(e0)) + __popcll(__ballot(e1)) + __popcll(__ballot(e2)) + __popcll(__ballot(e3));
-            if (cnt < 64 && cnt < total) break;             // not a hot bin: everyone for themselves
-            if (lane == 0) atomicAdd(&h[b], (unsigned)cnt);
-            if (cnt == total) return;
-            pend[0] = pend[0] && !e0; pend[1] = pend[1] && !e1; pend[2] = pend[2] && !e2; pend[3] = pend[3] && !e3;
-        }
+        for (int u = 0; u < 4; ++u)
+            if (pred[u]) atomicAdd(&h[bin[u]], 1u);
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-        if (pend[u]) atomicAdd(&h[bin[u]], 1u);
 }
+// (Round 4 measured a more general form -- the bin of the first pending element counted over the wave by ballots, one lane
+// adding the count, twice, stragglers for themselves: 114 -> 73-82 us on rows within a few ulps of 1, 70 -> 65 us on a two-bin
+// band, but 40 -> 50 us on spread-out rows and 42 -> 60 us inside the bench step, whose workgroups already run at the
+// 128-register limit: the extra ballots spill scalar registers.  Not kept.)
 
 // One chunk (QCHUNK elements = 8 float4 per thread of a 256-thread workgroup), split into "issue every load" and
 // "process": the passes put all global loads of a workgroup (data, mask values, histograms) in flight at once, so a

@@ -28,9 +28,6 @@ constexpr int SM_KEYS = 32 * SM_WAVES;                 // keys per workgroup til
 constexpr int SM_TILE_F = CH * 32;                     // floats of one wave's sub-tile (16 KB)
 constexpr int SM_Q_F = 32 * CH;                        // floats of the shared row image (16 KB)
 constexpr int SM_LDS = (SM_WAVES * SM_TILE_F + SM_Q_F + 3 * SM_WAVES * 32 + SM_WAVES * 64 + SM_WAVES * 32) * 4;
-// P1BF (product 1 as a three-way bf16 split, see below): the row image becomes three bf16 images of 8 KB each
-constexpr int SM_QB_F = 3 * 32 * CH / 2;               // floats' worth of LDS of the three bf16 row images (24 KB)
-constexpr int SM_LDS_BF = SM_LDS + (SM_QB_F - SM_Q_F) * 4;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -113,57 +110,6 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& 
         lo[j] = (__bf16)(v[j] - (float)hj);
     }
 }
-// Product 1 as a THREE-way bf16 split (P1BF): x = hi + mid + lo with bf16 parts (24 significant bits: exact up to the
-// last fp32 bit), every product a*b = hh + hm + mh + hl + lh + mm on v_mfma_f32_32x32x16_bf16 with fp32 accumulation;
-// the dropped terms (ml, lm, ll) are below 2^-24 |a||b|.  Six 32-cycle MFMAs per 16 channels instead of eight 64-cycle
-// f32 MFMAs, and -- unlike the f32-input MFMA, which blocks the VALU of the SIMD it runs on --
-// the bf16 matrix pipe runs beside the VALU, so one wave's soft-max section overlaps the other wave's product.
-__device__ __forceinline__ void split8x3(const float (&v)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const __bf16 hj = (__bf16)v[j];
-        const float r1 = v[j] - (float)hj;
-        const __bf16 mj = (__bf16)r1;
-        hi[j] = hj;
-        mid[j] = mj;
-        lo[j] = (__bf16)(r1 - (float)mj);
-    }
-}
-// B fragments of k-step G (channels 64 h + 8 G .. + 7 of this lane's row): one 16-byte chunk of each bf16 image
-template <int G>
-__device__ __forceinline__ void p1_read_rows_bf(f32x4 (&b)[3], const unsigned (&qa)[8]) {
-    lds_read_b128<0>(b[0], qa[G]);
-    lds_read_b128<8192>(b[1], qa[G]);
-    lds_read_b128<16384>(b[2], qa[G]);
-}
-template <int N>
-__device__ __forceinline__ void lds_wait8_3(float (&v)[8], f32x4 (&b)[3]) {
-    asm volatile("s_waitcnt lgkmcnt(%11)"
-                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(b[0]),
-                   "+v"(b[1]), "+v"(b[2])
-                 : "i"(N));
-}
-template <int G>
-__device__ __forceinline__ f32x16 p1_group_bf(f32x16 acc, float (&cur)[8], float (&nxt)[8], f32x4 (&bc)[3], f32x4 (&bn)[3],
-                                              const unsigned (&a1)[8], const unsigned (&qa)[8]) {
-    if constexpr (G + 1 < 8) {
-        p1_read_group<G + 1>(nxt, a1);
-        p1_read_rows_bf<G + 1>(bn, qa);
-        lds_wait8_3<11>(cur, bc);
-    } else {
-        lds_wait8_3<0>(cur, bc);
-    }
-    bf16x8 ah, am, al;
-    split8x3(cur, ah, am, al);
-    const bf16x8 bh = __builtin_bit_cast(bf16x8, bc[0]), bm = __builtin_bit_cast(bf16x8, bc[1]), bl = __builtin_bit_cast(bf16x8, bc[2]);
-    acc = mfma_bf(al, bh, acc);          // small terms first
-    acc = mfma_bf(ah, bl, acc);
-    acc = mfma_bf(am, bm, acc);
-    acc = mfma_bf(am, bh, acc);
-    acc = mfma_bf(ah, bm, acc);
-    acc = mfma_bf(ah, bh, acc);
-    return acc;
-}
 template <int N>
 __device__ __forceinline__ void p2_read(f32x4& v, const unsigned (&a2)[4]) {      // chunk N = 4 cb + g of this lane's channel
     lds_read_b128<(N >> 2) * 4096>(v, a2[N & 3]);
@@ -201,14 +147,14 @@ __device__ unsigned long long cp2_stamps[256 * 8 * 16];
 #define CP2_STAMP(i) do {} while (0)
 #endif
 
-template <bool WITH_U, bool P1BF>
+template <bool WITH_U>
 __global__ __launch_bounds__(64 * SM_WAVES) void rowkey_small_kernel(RowKeyArgs a, int tiles_per_wg, int stagger) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     float* T = sm + w * SM_TILE_F;
     float* Q = sm + SM_WAVES * SM_TILE_F;                       // shared row image
-    float* mbuf = Q + (P1BF ? SM_QB_F : SM_Q_F);                // [8][32] merge scratch: max, sum, count
+    float* mbuf = Q + SM_Q_F;                                   // [8][32] merge scratch: max, sum, count
     float* sbuf = mbuf + SM_WAVES * 32;
     int* cbuf = reinterpret_cast<int*>(sbuf + SM_WAVES * 32);
     float* ebuf = sbuf + 2 * SM_WAVES * 32 + w * 64;            // [8][64] this wave's positive logits
@@ -272,28 +218,6 @@ __global__ __launch_bounds__(64 * SM_WAVES) void rowkey_small_kernel(RowKeyArgs 
         pos_s = (row_ok && a.NE > 0) ? e * a.inv_t : INFINITY;
     }
     const unsigned qb = lds_addr(Q) + 16u * (unsigned)(r * 32 + ((h ^ (r >> 4)) << 4));
-    unsigned qa[8];                                             // P1BF: this lane's chunk of k-step G in the bf16 row images
-    if constexpr (P1BF) {
-        // fp32 row image -> three bf16 images (hi | mid | lo, 8 KB each, in place over the fp32 image + 8 KB): thread
-        // (row rr = tid / 16, chunk c8 = tid % 16) converts channels 8 c8 .. 8 c8 + 7; chunk c8 of row rr goes to the
-        // 16-byte slot rr * 16 + (c8 ^ (rr & 15)), which 16 consecutive lanes read without bank conflicts
-        const int rr = tid >> 4, c8 = tid & 15;
-        f32x4 x0, x1;
-        lds_read_b128<0>(x0, lds_addr(Q) + 16u * (unsigned)(rr * 32 + ((2 * c8) ^ rr)));
-        lds_read_b128<0>(x1, lds_addr(Q) + 16u * (unsigned)(rr * 32 + ((2 * c8 + 1) ^ rr)));
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1));
-        const float v8[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-        bf16x8 qh, qm, ql;
-        split8x3(v8, qh, qm, ql);
-        __syncthreads();                                        // every thread has read its part of the fp32 image
-        float* dst = Q + 4 * (rr * 16 + (c8 ^ (rr & 15)));
-        *reinterpret_cast<bf16x8*>(dst) = qh;
-        *reinterpret_cast<bf16x8*>(dst + 2048) = qm;
-        *reinterpret_cast<bf16x8*>(dst + 4096) = ql;
-        __syncthreads();
-#pragma unroll
-        for (int g = 0; g < 8; ++g) qa[g] = lds_addr(Q) + 16u * (unsigned)(r * 16 + ((8 * h + g) ^ (r & 15)));
-    }
 
     // product 1 read addresses: T[slot(64 h + t, r >> 2) * 4 + (r & 3)], rotation (kq + (t >> 1)) & 7 has period 8 in t >> 1
     const unsigned tbase = lds_addr(T);
@@ -320,21 +244,7 @@ __global__ __launch_bounds__(64 * SM_WAVES) void rowkey_small_kernel(RowKeyArgs 
 
         // product 1: S^T[key = rho(reg, h)][row = r]
         f32x16 acc = {0};
-        if constexpr (P1BF) {
-            float va[8], vb[8];
-            f32x4 ba[3], bb[3];
-            p1_read_group<0>(va, a1);
-            p1_read_rows_bf<0>(ba, qa);
-            CP2_STAMP(2);
-            acc = p1_group_bf<0>(acc, va, vb, ba, bb, a1, qa);
-            acc = p1_group_bf<1>(acc, vb, va, bb, ba, a1, qa);
-            acc = p1_group_bf<2>(acc, va, vb, ba, bb, a1, qa);
-            acc = p1_group_bf<3>(acc, vb, va, bb, ba, a1, qa);
-            acc = p1_group_bf<4>(acc, va, vb, ba, bb, a1, qa);
-            acc = p1_group_bf<5>(acc, vb, va, bb, ba, a1, qa);
-            acc = p1_group_bf<6>(acc, va, vb, ba, bb, a1, qa);
-            acc = p1_group_bf<7>(acc, vb, va, bb, ba, a1, qa);
-        } else {
+        {
             // B operand of product 1, re-read from the LDS row image for every sub-tile: 64 registers that are live
             // only during product 1 instead of across the whole loop
             f32x4 bq[CH / 8];                                   // bq[j][e] = this lane's row at channel 64 h + 4 j + e
@@ -508,16 +418,15 @@ int rowkey_small_num_splits(int K, int* tiles_per_wg) {
     return cp2_cdiv(tiles, tpw);
 }
 
-int rowkey_small_launch(const RowKeyArgs& a, int nsplit, bool with_u, bool p1_bf16, hipStream_t stream) {
+int rowkey_small_launch(const RowKeyArgs& a, int nsplit, bool with_u, hipStream_t stream) {
     int tpw = 1;
     if (rowkey_small_num_splits(a.K, &tpw) != nsplit) return CP2_ERR_SHAPE;
     using KFn = void (*)(RowKeyArgs, int, int);
-    const int v = (with_u ? 1 : 0) + (p1_bf16 ? 2 : 0);
-    static const KFn kfns[4] = {rowkey_small_kernel<false, false>, rowkey_small_kernel<true, false>,
-                                rowkey_small_kernel<false, true>, rowkey_small_kernel<true, true>};
+    const int v = with_u ? 1 : 0;
+    static const KFn kfns[2] = {rowkey_small_kernel<false>, rowkey_small_kernel<true>};
     const KFn kfn = kfns[v];
-    const int lds = p1_bf16 ? SM_LDS_BF : SM_LDS;
-    static bool attr_set[4] = {false, false, false, false};   // (idempotent cache of a per-function attribute, not library state)
+    const int lds = SM_LDS;
+    static bool attr_set[2] = {false, false};          // (idempotent cache of a per-function attribute, not library state)
     if (!attr_set[v]) {
         hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e_ != hipSuccess) return (int)e_;

@@ -86,6 +86,39 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
         super()._save_to_state_dict(destination, prefix, keep_vars)
 
 
+class SyncFusedBatchNorm2d(nn.SyncBatchNorm):
+    """torch.nn.SyncBatchNorm (batch statistics over all ranks: what Lightning's Trainer(sync_batchnorm=True) turns every
+    BatchNorm into, reference mirror_pretrain.py:229-231) with the (+ residual) (+ ReLU) call signature the ResNet blocks use."""
+
+    def forward(self, x, residual=None, relu=False):
+        y = super().forward(x)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu else y
+
+
+def convert_sync_batchnorm(module: nn.Module, process_group=None) -> nn.Module:
+    """Replace every FusedBatchNorm2d / BatchNorm2d below `module` by a SyncFusedBatchNorm2d holding the same parameters and
+    buffers (state-dict keys unchanged) -- torch.nn.SyncBatchNorm.convert_sync_batchnorm for modules whose forward takes
+    (x, residual, relu).  The fused single-rank BN kernels (csrc/bn.hip) see one rank's rows only; statistics over the
+    ranks go through torch's SyncBatchNorm (all-gather of per-channel mean / inverse std / count)."""
+    out = module
+    if isinstance(module, nn.BatchNorm2d) and not isinstance(module, nn.SyncBatchNorm):
+        out = SyncFusedBatchNorm2d(module.num_features, module.eps, module.momentum, module.affine, module.track_running_stats,
+                                   process_group)
+        if module.affine:
+            with torch.no_grad():
+                out.weight, out.bias = module.weight, module.bias
+        out.running_mean, out.running_var = module.running_mean, module.running_var
+        if isinstance(module, FusedBatchNorm2d) and module._pending_batches and module.num_batches_tracked is not None:
+            module.num_batches_tracked += module._pending_batches
+        out.num_batches_tracked = module.num_batches_tracked
+        out.training = module.training
+    for name, child in module.named_children():
+        out.add_module(name, convert_sync_batchnorm(child, process_group))
+    return out
+
+
 class _MaxPool3s2Fn(torch.autograd.Function):
     """MaxPool2d(3, 2, 1) of the stem on channels-last bf16 activations by csrc/pool.hip (one byte of argmax per output
     element, gather backward): 13 + 20 us instead of ATen's 35 + 85 us at 32 x 64 x 112 x 112."""

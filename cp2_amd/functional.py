@@ -71,14 +71,14 @@ class _CP2LossFn(torch.autograd.Function):
             neg = (nscale, None)
         elif ntype in (NEG_AVERAGE, NEG_MEDIAN):
             pre = ops.dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temp_local, ids, weights,
-                                        want_logits=(ntype == NEG_MEDIAN), want_batch=False)
+                                        want_logits=(ntype == NEG_MEDIAN))
             if ntype == NEG_AVERAGE:
                 centre = pre.sample_scal[:, 4].contiguous()
             else:
                 centre = ops.masked_quantiles(pre.logits, P * P, 1, B, P * P, mask_a=mask_a, mask_b=mask_b, want=0)[1].contiguous()
             neg = (nscale, centre)
         den = ops.dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temp_local, ids, weights, want_logits=want_quart,
-                                    negative=neg, want_batch=False)
+                                    negative=neg)
         if need_grad:
             # the dense kernel's split gradients stay un-summed: feat_bwd_fused adds them, and computes the pooled-vector
             # backward per workgroup (round 2: dense_grad_sum + pool_bwd + two fill kernels for dE)

@@ -65,6 +65,9 @@ def get_args(argv=None):
     parser.add_argument("--pretrain_type", choices=[x.name for x in PretrainType], default=PretrainType.RANDOM.name,
                         help='initialisation (the reference hard-codes NONE = ImageNet download; no network here)')
     parser.add_argument("--amp", choices=["bf16", "none"], default="none", help='the reference trains with precision=32')
+    parser.add_argument("--no_sync_batchnorm", action="store_true",
+                        help='more than one rank: keep BatchNorm statistics per rank (the reference syncs them: Trainer(sync_batchnorm=True))')
+    parser.add_argument("--dist_backend", type=str, default="nccl", help='torch.distributed backend (nccl = RCCL)')
     # fmt:on
     args = parser.parse_args(argv)
     args.log_dir = os.path.abspath(os.path.expanduser(args.log_dir))
@@ -121,7 +124,8 @@ def main(args):
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        from . import dist as cdist
+        cdist.init_process_group(args.dist_backend, rank, world)
     np.random.seed(args.seed + rank)
     torch.manual_seed(args.seed)
     train_u8, val_u8 = _load_images(args, device)
@@ -140,8 +144,12 @@ def main(args):
                            image_shape=(3, args.img_x_size, args.img_y_size), lmbd_compare_loss=args.lmbd_compare_loss,
                            softmax_temp=args.softmax_temp, mirror_variant=args.variant,
                            amp_dtype=torch.bfloat16 if args.amp == "bf16" else None).to(device)
-    # the reference's Trainer(sync_batchnorm=True) (:231) is not reproduced: BatchNorm statistics stay per rank
     step_mod = model
+    if world > 1 and not args.no_sync_batchnorm:
+        # the reference's Trainer(sync_batchnorm=True) (mirror_pretrain.py:229-231): batch statistics over all ranks
+        from .encoder import convert_sync_batchnorm
+        model = convert_sync_batchnorm(model)
+        step_mod = model
     if world > 1:
         # broadcast_buffers=False: the confusion counts are per-rank tallies (summed over ranks in MirrorModule.metrics);
         # DDP's default would overwrite them with rank 0's on every forward

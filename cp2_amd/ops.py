@@ -582,21 +582,18 @@ def rowkey_infonce(rows: torch.Tensor, row_layout: Tuple[int, int, int, int], R:
     grad_scale None -> forward only; else drows (same layout, allocated like `drows_like` or
     `rows`) and dE carry grad_scale * d(sum_r loss_r)/d(rows, extras).
     precision: "f32" (exact fp32 on the f32-input MFMA), "bf16x3" (split-bf16, logits within 3e-5, ~3x faster when
-    MFMA-bound), "bf16x6" (at most 32 rows: every operand as three bf16 parts, six products -- logits within 2e-7 of
-    the exact fp32 value; measured no faster than "f32" at 32 x 65536, where the kernel waits for the queue stream, so
-    it is an option, not the default) or "auto" = bf16x3 from 1024 rows up (the DenseCL per-pixel case), f32 below.
+    MFMA-bound; K % 16 == 0, else the f32 kernel serves the call) or "auto" = bf16x3 from 1024 rows up (the DenseCL
+    per-pixel case), f32 below.
     For callers that walk the rows in several calls (the chunked DenseCL statistics): `ksplit` = the bf16x3 workspace to
     use (4*C*K bf16; `ksplit_ready`: an earlier call on this stream already filled it for this queue), `lneg_out` = the
     buffer (>= R*K floats) that receives the raw logits, `drows_out` = where the row gradient goes (a view in the rows'
     layout)."""
-    if precision not in ("auto", "f32", "bf16x3", "bf16x6"):
+    if precision not in ("auto", "f32", "bf16x3"):
         raise ValueError(f"precision {precision!r}")
-    if precision == "bf16x6" and R > 32:
-        raise ValueError("precision 'bf16x6' is the small-R kernel's mode (R <= 32)")
     if precision == "auto":
         prec = 1 if R >= 1024 else 0
     else:
-        prec = {"f32": 0, "bf16x3": 1, "bf16x6": 2}[precision]
+        prec = {"f32": 0, "bf16x3": 1}[precision]
     lib = _lib.load()
     C, K = keys.shape
     RP, sn, sx, sc = row_layout
@@ -622,7 +619,7 @@ def rowkey_infonce(rows: torch.Tensor, row_layout: Tuple[int, int, int, int], R:
         out.lnegT = torch.empty((K, R), dtype=torch.float32, device=dev)
     lbuf = out.lneg if out.lneg is not None else out.lnegT
     # bf16x3: the queue's hi/lo split in both layouts, written once per call by a prep kernel (4*C*K bf16)
-    if not (prec == 1 and R > 64 and K % 8 == 0 and presplit):
+    if not (prec == 1 and R > 64 and K % 16 == 0 and presplit):
         ksplit, ksplit_ready = None, False
     elif ksplit is None:
         ksplit, ksplit_ready = torch.empty(4 * C * K, dtype=torch.bfloat16, device=dev), False
@@ -728,7 +725,15 @@ def densecl_match(q_embed: torch.Tensor, k_embed: torch.Tensor, q_local: torch.T
 
 # ---------------------------------------------------------------- a8 / a9
 class DenseResult:
-    __slots__ = ("loss", "acc", "lse", "sample_scal", "colmax", "argx", "logits")
+    __slots__ = ("lse", "sample_scal", "colmax", "argx", "logits")
+
+    @property
+    def loss(self):          # mean_n loss_n (builder.py:1431-1437)
+        return self.sample_scal[:, 2].mean()
+
+    @property
+    def acc(self):           # 100 * mean_n arg-max label (builder.py:1442-1448)
+        return 100.0 * self.sample_scal[:, 5].mean()
 
 
 def _ids4(ids):
@@ -749,8 +754,10 @@ def _negative(negative):
 
 
 def dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temperature: float, ids=None,
-                      weights=(1.0, 1.0, 1.0), want_logits: bool = False, split: bool = True, negative=None,
-                      want_batch: bool = True) -> DenseResult:
+                      weights=(1.0, 1.0, 1.0), want_logits: bool = False, split: bool = True, negative=None) -> DenseResult:
+    """Per-sample results in sample_scal [B,8] (Sa, Sb, loss_n, mean +score, mean -score, arg-max label): the batch means
+    are formed by cp2_step_scalars in the step (`loss` / `acc` below are those means taken with tensor ops, for callers
+    outside the step)."""
     lib = _lib.load()
     nmode, nscale, ncen = _negative(negative)
     B, C, P = q_dense.shape
@@ -760,7 +767,6 @@ def dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temperature: float, ids=
     res.lse, colsum, possum, allsum, res.colmax = f(), f(), f(), f(), f()
     res.argx = torch.empty((B, P), dtype=torch.int32, device=dev)
     res.sample_scal = torch.empty((B, 8), dtype=torch.float32, device=dev)
-    batch = torch.empty(2, dtype=torch.float32, device=dev) if want_batch else None    # None: cp2_step_scalars forms the means
     res.logits = torch.empty((B, P, P), dtype=torch.float32, device=dev) if want_logits else None
     pa, pb, ra, rb = _ids4(ids)
     S = lib.cp2_dense_num_splits(B, P) if split else 1
@@ -771,24 +777,24 @@ def dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temperature: float, ids=
                                    pa, pb, ra, rb, float(weights[0]), float(weights[1]), float(weights[2]),
                                    float(temperature), res.lse.data_ptr(), colsum.data_ptr(), possum.data_ptr(),
                                    allsum.data_ptr(), res.colmax.data_ptr(), res.argx.data_ptr(),
-                                   res.sample_scal.data_ptr(), _opt(batch, "batch"), _opt(res.logits, "logits"),
+                                   res.sample_scal.data_ptr(), _opt(res.logits, "logits"),
                                    split_ws.data_ptr() if split_ws is not None else None, nmode, nscale, ncen, B, C, P, _stream())
     _lib.check(rc, "cp2_dense_infonce_fwd")
-    res.loss, res.acc = (batch[0], batch[1]) if want_batch else (None, None)
     return res
 
 
 def dense_infonce_bwd(q_dense, k_dense, mask_a, mask_b, temperature: float, fwd: DenseResult, grad_scale: float,
                       ids=None, weights=(1.0, 1.0, 1.0), split: bool = True, negative=None, keep_partials: bool = False):
-    """d loss / d q_dense.  keep_partials: return (g_part, S) -- the S split gradients [S,B,C,P] un-summed (feat_bwd_fused
-    adds them), or the gradient itself with S = 1 when the shape needs no split."""
+    """d loss / d q_dense.  keep_partials (the step): return (g_part, S) -- the S split gradients [S,B,C,P] un-summed
+    (cp2_feat_bwd_fused adds them, in split order), or the gradient itself with S = 1 when the shape needs no split.
+    Otherwise the partials are added here with one tensor op (same order; for callers outside the step)."""
     lib = _lib.load()
     nmode, nscale, ncen = _negative(negative)
     B, C, P = q_dense.shape
     pa, pb, ra, rb = _ids4(ids)
     S = lib.cp2_dense_num_splits(B, P) if split else 1
     split_ws = torch.empty((S, B, C, P), dtype=torch.float32, device=q_dense.device) if S > 1 else None
-    g = None if (keep_partials and S > 1) else torch.empty_like(q_dense)
+    g = None if S > 1 else torch.empty_like(q_dense)
     _profile("dense_bwd")
     rc = lib.cp2_dense_infonce_bwd(_dev(q_dense, "q_dense"), _dev(k_dense, "k_dense"), _dev(mask_a, "mask_a"),
                                    _dev(mask_b, "mask_b"), pa, pb, ra, rb, float(weights[0]), float(weights[1]),
@@ -798,6 +804,10 @@ def dense_infonce_bwd(q_dense, k_dense, mask_a, mask_b, temperature: float, fwd:
     _lib.check(rc, "cp2_dense_infonce_bwd")
     if keep_partials:
         return (split_ws, S) if S > 1 else (g, 1)
+    if S > 1:                                             # sum_s in split order, as feat_bwd_fused does
+        g = split_ws[0].clone()
+        for sp in range(1, S):
+            g += split_ws[sp]
     return g
 
 

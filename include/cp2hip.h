@@ -179,12 +179,10 @@ int cp2_step_scalars(const float* ins_loss, const int32_t* cnt_gt, const float* 
  * part_cnt [nsplit,R] int32, part_U [nsplit,C,R] (NULL: no gradient), lnegT: NULL, or the raw logits rows.keys as
  * [K,R] (lneg_row_major = 0) or [R,K] (lneg_row_major = 1, the layout cp2_masked_quantiles reads fastest).
  * precision 0: f32-input MFMA (exact fp32 fma chains, logits within ~1e-6 of the reference);
- * precision 2: R <= 32 only: three-way bf16 split of both operands, six products on bf16 MFMA with fp32 accumulation
- *              (logits within 2e-7 of the exact fp32 value); other R: as precision 0;
  * precision 1: split-bf16 (hi*hi + hi*lo + lo*hi on bf16 MFMA, fp32 accumulate; logits within 3e-5) -- used when
- *              R > 64, otherwise the f32 kernel runs regardless.  keys_split: NULL, or a workspace of 4*C*K bf16
- *              (16-byte aligned, K % 8 == 0) that receives the hi/lo split of the queue in both layouts once per call;
- *              with it the main kernel fills LDS by 16-byte copies instead of converting in every row block;
+ *              R > 64 with keys_split given and K % 16 == 0, otherwise the f32 kernel runs regardless.  keys_split: a workspace
+ *              of 4*C*K bf16 (16-byte aligned) that receives the hi/lo split of the queue in both layouts once per call:
+ *              the main kernel fills LDS from it by LDS-DMA;
  * precision 3: as 1, but keys_split already holds the split of this queue (written by an earlier precision-1 call on the
  *              same stream): the prep launch is skipped -- for callers that walk the rows in several calls. */
 int cp2_rowkey_num_splits(int R, int K);
@@ -209,8 +207,7 @@ int cp2_rowkey_infonce_finalize(const float* part_m, const float* part_s, const 
  * (pixel match -> w_pixel, else known-region match -> w_region, else w_not); NULL = all weights 1.
  * Per key pixel outputs [B,P]: lse, colsum_a, possum, allsum, colmax, argx (workspaces kept for backward /
  * logging).  sample_scal [B,8] = {Sa, Sb, loss_n, mean positive score, mean negative score, label at the
- * arg-max pair, 0, 0};  batch_out[2] = {mean_n loss_n, 100 * mean_n label}, or NULL when the caller forms the batch
- * means itself (cp2_step_scalars).
+ * arg-max pair, 0, 0}; the batch means (loss, arg-max accuracy) are formed by cp2_step_scalars.
  * logits_out: NULL, or [B,P,P] to also receive the raw logits q.k (only for the logging quantiles).   C = 128.
  * split_ws: NULL (one workgroup per (sample, 128-key tile) walks all query pixels), or float[7 * S * B * P] with
  * S = cp2_dense_num_splits(B, P): S workgroups share the walk and a merge kernel folds their partial statistics, so
@@ -224,13 +221,13 @@ int cp2_dense_infonce_fwd(const float* q_dense, const float* k_dense, const floa
                           const int64_t* pix_a, const int64_t* pix_b, const int64_t* reg_a, const int64_t* reg_b,
                           float w_pixel, float w_region, float w_not, float temperature, float* lse,
                           float* colsum_a, float* possum, float* allsum, float* colmax, int32_t* argx,
-                          float* sample_scal, float* batch_out, float* logits_out, float* split_ws,
+                          float* sample_scal, float* logits_out, float* split_ws,
                           int negative_mode, float negative_scale, const float* negative_center, int B, int C,
                           int P, void* stream);
 /* g_dense [B,C,P] = grad_scale * d (sum_n loss_n) / d q_dense, recomputing the logits tile by tile.
- * split_ws: NULL, or float[S * B * C * P] with S = cp2_dense_num_splits(B, P): the key-pixel range is shared by S
- * workgroups and their partial gradients are added in split order (deterministic).  g_dense may be NULL when split_ws
- * is given and S > 1: the S partial gradients [S][B][C][P] stay in split_ws for cp2_feat_bwd_fused to add. */
+ * split_ws: NULL (g_dense receives the gradient), or float[S * B * C * P] with S = cp2_dense_num_splits(B, P): the
+ * key-pixel range is shared by S workgroups; with S > 1 g_dense must be NULL and the S partial gradients [S][B][C][P]
+ * stay in split_ws for cp2_feat_bwd_fused to add in split order (deterministic); S == 1: g_dense as without split_ws. */
 int cp2_dense_infonce_bwd(const float* q_dense, const float* k_dense, const float* mask_a, const float* mask_b,
                           const int64_t* pix_a, const int64_t* pix_b, const int64_t* reg_a, const int64_t* reg_b,
                           float w_pixel, float w_region, float w_not, float temperature, const float* lse,

@@ -62,6 +62,47 @@ def _worker(rank, world, port, out_dir, mode="torch-sgd"):
             torch.save({"ok": True}, os.path.join(out_dir, f"r{rank}.pt"))
             dist.barrier()
             return
+        if mode == "sync-bn":
+            # the mirror path with more than one rank (reference mirror_pretrain.py:229-231, sync_batchnorm=True): every
+            # BatchNorm of the encoder takes its batch statistics over ALL ranks -- outputs and running statistics equal
+            # one process running plain BatchNorm on the concatenated batch
+            from cp2_amd.encoder import SyncFusedBatchNorm2d, build_segmentor, convert_sync_batchnorm
+            torch.manual_seed(3)
+            ref = build_segmentor(cfg.model).to(dev).train()
+            net = build_segmentor(cfg.model).to(dev).train()
+            net.load_state_dict(ref.state_dict())
+            keys = list(net.state_dict())
+            net = convert_sync_batchnorm(net)
+            assert list(net.state_dict()) == keys                               # same state-dict keys
+            n_sync = sum(isinstance(m, SyncFusedBatchNorm2d) for m in net.modules())
+            assert n_sync > 15 and not any(type(m).__name__ == "FusedBatchNorm2d" for m in net.modules())
+            xs = [torch.randn(3, 3, 64, 64, device=dev, generator=torch.Generator(dev).manual_seed(50 + r)) for r in range(world)]
+            y = net(xs[rank])
+            y_ref = ref(torch.cat(xs))[3 * rank:3 * rank + 3]
+            assert (y - y_ref).abs().max().item() <= 2e-4 * y_ref.abs().max().item() + 1e-6
+            a, b2 = net.backbone.layer2[0].bn1, ref.backbone.layer2[0].bn1
+            assert torch.allclose(a.running_mean, b2.running_mean, atol=1e-5) and torch.allclose(a.running_var, b2.running_var, rtol=1e-4, atol=1e-6)
+            torch.save({"ok": True}, os.path.join(out_dir, f"r{rank}.pt"))
+            dist.barrier()
+            return
+        if mode == "score-stats":
+            # the DenseCL score statistics shared out over the ranks (builder.row_score_stats_over_ranks) == the same
+            # statistics taken by one rank alone over rank 0's rows: per-row results bit for bit, so the means agree to 1e-6
+            from cp2_amd import ops
+            g = torch.Generator(dev).manual_seed(1000 + rank)                  # every rank holds different rows
+            rows = torch.nn.functional.normalize(torch.randn(5, 128, 49, device=dev, generator=g), dim=1)
+            queue = torch.nn.functional.normalize(torch.randn(128, 2048, device=dev, generator=torch.Generator(dev).manual_seed(7)), dim=0)
+            got = builder.row_score_stats_over_ranks(rows, queue)
+            src = rows.clone()
+            dist.broadcast(src, 0)
+            res = ops.rowkey_infonce(src, (49, 128 * 49, 1, 49), 5 * 49, queue, torch.zeros(5 * 49, 1, device=dev), 1.0,
+                                     grad_scale=None, want_lneg=True, lneg_row_major=True, precision="f32")
+            q = ops.masked_quantiles(res.lneg, 2048, 1, 5 * 49, 2048)
+            want = torch.cat([res.lneg.mean(1).mean().reshape(1), q.mean(1)])
+            assert (got - want).abs().max().item() <= 1e-6, (got, want)
+            torch.save({"ok": True, "stats": got.cpu()}, os.path.join(out_dir, f"r{rank}.pt"))
+            dist.barrier()
+            return
         if mode == "flat-gather-allgather":
             model.shuffle_exchange = "all_gather"
         if mode in ("flat-inline", "densecl-v2", "flatddp-vs-ddp"):     # cp2_amd.ddp.FlatDDP: what main.py / bench.py use by default
@@ -118,8 +159,7 @@ def _worker(rank, world, port, out_dir, mode="torch-sgd"):
             from cp2_amd.optim import FlatSGD
             opt = FlatSGD(ddp, 0.01, momentum=0.9, weight_decay=1e-4)
             # "flat-inline": the default (everything in order on one stream); the side-stream forms stay covered
-            model.overlap_key_branch = {"flat-inline": None, "flat-gather": "gather", "flat-gather-allgather": "gather",
-                                        "flat-branch": True}[mode]
+            model.overlap_key_branch = {"flat-inline": None, "flat-gather": "gather", "flat-gather-allgather": "gather"}[mode]
             steps = 6
         b = 6
         for step in range(steps):
@@ -129,7 +169,7 @@ def _worker(rank, world, port, out_dir, mode="torch-sgd"):
             loss.backward()
             opt.step()
             assert torch.isfinite(loss)
-        assert (model._side_stream is not None) == (mode in ("flat-gather", "flat-gather-allgather", "flat-branch"))
+        assert (model._side_stream is not None) == (mode in ("flat-gather", "flat-gather-allgather"))
         if mode.startswith("flat"):
             assert model._key_graph is not None and any(e["graph"] is not None for e in model._key_graph.entries.values())
         torch.cuda.synchronize()
@@ -143,7 +183,7 @@ def _worker(rank, world, port, out_dir, mode="torch-sgd"):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("mode", ["torch-sgd", "flat-inline", "flat-gather", "flat-gather-allgather", "flat-branch", "densecl", "densecl-v2"])
+@pytest.mark.parametrize("mode", ["torch-sgd", "flat-inline", "flat-gather", "flat-gather-allgather", "densecl", "densecl-v2"])
 def test_two_ranks_one_device_gloo(tmp_path, mode):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), mode), nprocs=world, join=True)
@@ -158,6 +198,19 @@ def test_two_ranks_one_device_gloo(tmp_path, mode):
 def test_flat_ddp_gradients_are_the_rank_average_of_this_backward_pass(tmp_path):
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), "flatddp-vs-ddp"), nprocs=2, join=True)
     assert torch.load(tmp_path / "r0.pt")["ok"] and torch.load(tmp_path / "r1.pt")["ok"]
+
+
+@pytest.mark.timeout(300)
+def test_sync_batchnorm_conversion_equals_one_process_on_the_whole_batch(tmp_path):
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), "sync-bn"), nprocs=2, join=True)
+    assert torch.load(tmp_path / "r0.pt")["ok"] and torch.load(tmp_path / "r1.pt")["ok"]
+
+
+@pytest.mark.timeout(300)
+def test_score_statistics_shared_over_ranks_equal_one_rank(tmp_path):
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), "score-stats"), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert r0["ok"] and r1["ok"] and torch.equal(r0["stats"], r1["stats"])     # the all-reduce leaves them on every rank
 
 
 @pytest.mark.timeout(300)

@@ -418,29 +418,6 @@ def _masked_quantiles_cases():
     assert np.array_equal(neg.cpu().numpy(), st["negative"]["quartiles"].numpy(), equal_nan=True)
 
 
-@pytest.mark.parametrize("R_rows,K", [(32, 65536), (7, 4096)])
-def test_rowkey_small_bf16x6_vs_oracle(R_rows, K):
-    """Three-way bf16 split of product 1 in the <= 32-row kernel (six bf16 MFMAs per product): same bounds as the exact
-    fp32 mode -- raw logits 2e-6, loss 2e-5, gradients 2e-5 * max (measured: 2e-7 against fp64, like the fp32 chain)."""
-    gen = torch.Generator().manual_seed(R_rows + K)
-    C, T = 128, 0.2
-    rows = torch.nn.functional.normalize(torch.randn(R_rows, C, generator=gen), dim=1)
-    queue = torch.nn.functional.normalize(torch.randn(C, K, generator=gen), dim=0)
-    pos = torch.rand(R_rows, generator=gen) * 2 - 1
-    r_cpu, p_cpu = rows.clone().requires_grad_(True), pos.clone().requires_grad_(True)
-    want = O.queue_infonce(r_cpu, p_cpu, queue, T)
-    want.backward()
-    got = ops.rowkey_infonce(rows.to(DEV), (1, C, 0, 1), R_rows, queue.to(DEV), pos.reshape(-1, 1).to(DEV), T,
-                             grad_scale=1.0 / R_rows, want_lneg=True, lneg_row_major=True, precision="bf16x6")
-    assert_close(got.lneg, rows @ queue, 2e-6, what="raw logits")
-    assert_close(got.loss, want.detach(), 2e-5, what="loss")
-    assert_close(got.drows, r_cpu.grad, 1e-9, 2e-5, "d rows")
-    assert_close(got.dE[:, 0], p_cpu.grad, 1e-9, 2e-5, "d pos")
-    with pytest.raises(ValueError):
-        ops.rowkey_infonce(rows.to(DEV).repeat(8, 1), (1, C, 0, 1), 8 * R_rows, queue.to(DEV), pos.repeat(8).reshape(-1, 1).to(DEV), T,
-                           grad_scale=None, precision="bf16x6")
-
-
 @pytest.mark.parametrize("R_rows,K", [(640, 8192), (200, 1000), (4096, 4096)])
 def test_rowkey_bf16x3_vs_oracle(R_rows, K):
     """Split-bf16 mode of the rows-vs-queue kernel (hi*hi + hi*lo + lo*hi on bf16 MFMA): north_star's bound is fp32
