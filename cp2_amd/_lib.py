@@ -39,6 +39,8 @@ SIGNATURES = {
     "cp2_feat_bwd_fused": [_P, _P, _P, _P, c_int, c_int64, _P, _P, c_int, _P, _P, _P, _P, _P, c_int, _P, c_int64, c_int64, c_int64,
                            c_int, c_int, c_int, _P],
     "cp2_step_scalars": [_P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, c_float, _P, c_int, c_int, _P],
+    "cp2_step_tail": [_P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, c_float, _P, c_int, c_int,
+                      _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
     "cp2_rowkey_num_splits": [c_int, c_int],
     "cp2_rowkey_infonce_fwd": [_P, c_int, c_int64, c_int64, c_int64, c_int, _P, c_int, _P, c_int, c_float,
                                c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, c_int, _P],

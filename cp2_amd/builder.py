@@ -630,6 +630,18 @@ class MODEL(nn.Module):
             torch.cuda.current_stream().wait_event(ev)
             self._enqueue_done = None
 
+    def _gather_keys(self, keys):
+        """All ranks' keys in rank order (C4, reference builder.py:572), timed as the step's key gather."""
+        with self._comm("c4_key_gather_enqueue"):
+            return concat_all_gather(keys.contiguous())
+
+    def _keep_ious(self, iou, iou_masked):
+        self.correlation_ious.append(iou)
+        self.masked_correlation_ious.append(iou_masked)
+        if len(self.correlation_ious) >= 1024:              # keep the python lists short (device-side concatenation, no sync)
+            self.correlation_ious[:] = [torch.cat(self.correlation_ious)]
+            self.masked_correlation_ious[:] = [torch.cat(self.masked_correlation_ious)]
+
     def _dequeue_and_enqueue(self, keys):
         self._enqueue(self.queue, self.queue_ptr, keys)
 
@@ -759,13 +771,11 @@ class MODEL(nn.Module):
         weights = (float(self.lmbd_pixel_corr_weight), float(self.lmbd_region_corr_weight), float(self.lmbd_not_corr_weight))
         if weights != (1.0, 1.0, 1.0):
             ids = tuple(ops.strided_gather(t.contiguous(), s).reshape(b, -1) for t in (pixel_ids_a, pixel_ids_b, region_ids_a, region_ids_b))
-        # IoUs of the down-sampled region-id maps, read straight from the full-resolution maps (logged per epoch, on device)
-        iou, iou_masked = ops.corr_iou_strided(region_ids_a.contiguous(), region_ids_b.contiguous(), s, mask_a, mask_b)
-        self.correlation_ious.append(iou)
-        self.masked_correlation_ious.append(iou_masked)
-        if len(self.correlation_ious) >= 1024:              # keep the python lists short (device-side concatenation, no sync)
-            self.correlation_ious[:] = [torch.cat(self.correlation_ious)]
-            self.masked_correlation_ious[:] = [torch.cat(self.masked_correlation_ious)]
+        # IoUs of the down-sampled region-id maps, read straight from the full-resolution maps (logged per epoch, on device):
+        # part of the step's tail launch when their hash table fits LDS (cp2_step_tail), else a launch of their own
+        iou_in_tail = ops.tail_iou_supported(H, W, s)
+        if not iou_in_tail:
+            self._keep_ious(*ops.corr_iou_strided(region_ids_a.contiguous(), region_ids_b.contiguous(), s, mask_a, mask_b))
 
         # The key branch (EMA -> shuffle-BN exchange -> key encoder -> un-shuffle) does not depend on the query encoder
         # (reference order builder.py:1260-1277 is serial).  overlap_key_branch:
@@ -828,12 +838,22 @@ class MODEL(nn.Module):
                     img_k.record_stream(cur)          # allocated on the side stream, read on this one
                 k, k_row = exchange_out(self._encode_key(img_k), ctx)
 
+        # the step's tail -- returned / logged scalars, the keys' enqueue (after the all-gather over the ranks, C4) and the
+        # logged IoUs -- is one launch; with the exchange steps on a side stream the enqueue stays with them (_enqueue)
+        tail = {}
+        if not mode and not torch.cuda.is_current_stream_capturing():
+            tail["enqueue"] = (self.queue_ptr, self._gather_keys if multi else None)
+        if iou_in_tail:
+            tail["iou"] = (region_ids_a.contiguous(), region_ids_b.contiguous(), s)
         out = CF.cp2_loss_section(q, k, mask_a, mask_b, self.queue, temp_global=self.temp_global,
                                   temp_local=self.temp_local, lmbd_dense=self.lmbd_dense_loss,
                                   include_background=self.include_background, ids=ids, weights=weights,
                                   want_quartiles=self.log_quartiles, negative_type=self.negative_type.value,
-                                  negative_scale=self.negative_scale, k_row=k_row)
-        self._dequeue_and_enqueue(out.k_pos)
+                                  negative_scale=self.negative_scale, k_row=k_row, tail=tail)
+        if "enqueue" not in tail:
+            self._dequeue_and_enqueue(out.k_pos)
+        if iou_in_tail:
+            self._keep_ious(out.iou, out.iou_masked)
         # the logged scalars come out of the loss section as one device vector (cp2_step_scalars); names as the
         # reference's wandb.log (builder.py:1553-1604)
         names = _CP2_LOG_NAMES_Q if self.log_quartiles else _CP2_LOG_NAMES

@@ -77,73 +77,10 @@ __global__ __launch_bounds__(1024) void corr_iou_kernel(const int64_t* __restric
     }
 }
 
-// The same counts without a sort, for maps of up to 2047 cells per side (the training shapes: P = 196 ... 1024): the
-// 2P+1 keys go into an open-addressing table in LDS (key bits + multiplicity per slot, load factor <= 1/2);
-//   union = #occupied slots - 1 (the zero key is always present),  intersection = #slots of a non-zero key hit >= 2 times.
-// The bitonic network above needs 45 barrier stages for 512 keys (16-18 us per launch, latency); this form needs two.
-// Integer counting only: bit-equal to the sorted form (and to the reference's torch.unique arithmetic) by construction.
-__global__ __launch_bounds__(256) void corr_iou_hash_kernel(const int64_t* __restrict__ ids_a, const int64_t* __restrict__ ids_b,
-                                                            const float* __restrict__ mask_a, const float* __restrict__ mask_b,
-                                                            float* __restrict__ iou, float* __restrict__ iou_masked, int P, int T,
-                                                            int H, int W, int stride, int Ws) {
-    extern __shared__ __attribute__((aligned(16))) unsigned tab[];      // [T] key bits | [T] multiplicities
-    __shared__ int red[2][4];
-    constexpr unsigned kEmpty = 0xFFFFFFFFu;                             // a NaN pattern: never a key
-    const int n = blockIdx.x;
-    const bool masked = blockIdx.y == 1;
-    float* out = masked ? iou_masked : iou;
-    if (!out) return;
-    unsigned* keys = tab;
-    unsigned* cnt = tab + T;
-    for (int i = threadIdx.x; i < T; i += 256) { keys[i] = kEmpty; cnt[i] = 0; }
-    __syncthreads();
-    auto at = [&](int p) -> int64_t {
-        if (stride <= 0) return (int64_t)n * P + p;
-        const int off = stride >> 1;
-        return ((int64_t)n * H + off + (int64_t)stride * (p / Ws)) * W + off + (int64_t)stride * (p % Ws);
-    };
-    const int nvalid = 2 * P + 1;
-    int shift = 0;
-    while ((1 << shift) < T) ++shift;
-    for (int i = threadIdx.x; i < nvalid; i += 256) {
-        float v = 0.0f;
-        if (i >= 1 && i <= P) {
-            const float idf = (float)(ids_a[at(i - 1)] + 1);
-            v = masked ? __fmul_rn(idf, mask_a[(int64_t)n * P + (i - 1)]) : idf;
-        } else if (i > P) {
-            const float idf = (float)(ids_b[at(i - 1 - P)] + 1);
-            v = masked ? __fmul_rn(idf, mask_b[(int64_t)n * P + (i - 1 - P)]) : idf;
-        }
-        if (v == 0.0f) v = 0.0f;                                        // -0.0 and +0.0 are one key (torch.unique compares values)
-        const unsigned bits = __float_as_uint(v);
-        unsigned slot = (bits * 2654435761u) >> (32 - shift);
-        for (int probe = 0; probe < T; ++probe) {
-            const unsigned prev = atomicCAS(&keys[slot], kEmpty, bits);
-            if (prev == kEmpty || prev == bits) { atomicAdd(&cnt[slot], 1u); break; }
-            slot = (slot + 1) & (unsigned)(T - 1);
-        }
-    }
-    __syncthreads();
-    int uniq = 0, inter = 0;
-    for (int i = threadIdx.x; i < T; i += 256) {
-        const unsigned k = keys[i];
-        if (k != kEmpty) {
-            ++uniq;
-            if (k != 0u && cnt[i] >= 2u) ++inter;
-        }
-    }
-    uniq = wave_sum_i(uniq);
-    inter = wave_sum_i(inter);
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { red[0][w] = uniq; red[1][w] = inter; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int u = 0, sI = 0;
-        for (int i = 0; i < 4; ++i) { u += red[0][i]; sI += red[1][i]; }
-        const int uni = u - 1;                                          // minus the zero key
-        out[n] = uni > 0 ? (float)((double)sI / (double)uni) : NAN;
-    }
-}
+// Maps of up to 2047 cells per side (the training shapes) are counted in an LDS hash table instead: tail.hip.
+int cp2_tail_iou_table(int P);
+int cp2_tail_iou_launch(const int64_t* ids_a, const int64_t* ids_b, const float* mask_a, const float* mask_b, float* iou,
+                        float* iou_masked, int B, int P, int H, int W, int stride, int Ws, void* stream);
 
 static int corr_iou_launch(const int64_t* ids_a, const int64_t* ids_b, const float* mask_a, const float* mask_b, float* iou,
                            float* iou_masked, int B, int P, int H, int W, int stride, int Ws, void* stream) {
@@ -152,20 +89,10 @@ static int corr_iou_launch(const int64_t* ids_a, const int64_t* ids_b, const flo
     if (iou_masked && (!mask_a || !mask_b)) return CP2_ERR_NULL;
     if (B <= 0 || P <= 0) return CP2_ERR_SHAPE;
     if (P > 16383) return CP2_ERR_UNSUPPORTED;
+    if (cp2_tail_iou_table(P) > 0)                           // hash-count form (two barriers instead of 45 sort stages)
+        return cp2_tail_iou_launch(ids_a, ids_b, mask_a, mask_b, iou, iou_masked, B, P, H, W, stride, Ws, stream);
     int N2 = 64;
     while (N2 < 2 * P + 1) N2 <<= 1;
-    if (N2 <= 4096) {                                       // hash-count form: table of 2 * N2 slots (key + multiplicity), <= 64 KB
-        const int T = 2 * N2;
-        const size_t tl = (size_t)2 * T * sizeof(unsigned);
-        if (tl > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_iou_hash_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl);
-            if (e != hipSuccess) return (int)e;
-        }
-        hipLaunchKernelGGL(corr_iou_hash_kernel, dim3(B, 2), dim3(256), tl, cp2_stream(stream), ids_a, ids_b, mask_a, mask_b, iou,
-                           iou_masked, P, T, H, W, stride, Ws);
-        return cp2_launch_status();
-    }
     const size_t lds = (size_t)N2 * sizeof(float);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_iou_kernel),

@@ -40,6 +40,8 @@ class CP2LossOutputs:
     instance_neg_quartiles: Optional[torch.Tensor] = None # builder.py:1401-1406
     instance_neg_mean: Optional[torch.Tensor] = None      # [B] builder.py:1400
     scalars: Optional[torch.Tensor] = None                # [24] every returned / logged scalar (cp2_step_scalars layout, S_* indices)
+    iou: Optional[torch.Tensor] = None                    # [B] IoU / masked IoU of the down-sampled region-id maps (tail["iou"])
+    iou_masked: Optional[torch.Tensor] = None
 
 
 # positions in the cp2_step_scalars vector (include/cp2hip.h)
@@ -50,7 +52,7 @@ S_VAR_SRC, S_VAR_TGT, S_DPOS_Q, S_DNEG_Q, S_INS_Q, S_INS_NEG_MEAN = 9, 10, 11, 1
 class _CP2LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q_feat, k_feat, mask_a, mask_b, queue, cfg):
-        (temp_global, temp_local, lmbd_dense, include_background, ids, weights, want_lneg, want_quart, negative, k_row) = cfg
+        (temp_global, temp_local, lmbd_dense, include_background, ids, weights, want_lneg, want_quart, negative, k_row, tail) = cfg
         want_lneg = want_lneg or want_quart
         B = q_feat.shape[0]
         need_grad = q_feat.requires_grad
@@ -97,13 +99,27 @@ class _CP2LossFn(torch.autograd.Function):
             qs = ops.masked_quantiles_multi([dict(dense, want=1), dict(dense, want=0),       # one launch for all three
                                              dict(x=ins.lneg, stride_row=K, stride_elem=1, R=B, N=K,
                                                   mean_out=lneg_mean if row_form else None)])
-        # every scalar the step returns or logs: one launch (the loss combination included)
-        scal = ops.step_scalars(ins.loss, ins.cnt_gt, ext, den.sample_scal, q_pos, k_pos, lmbd_dense, qs[0], qs[1], qs[2], lneg_mean)
+        # every scalar the step returns or logs: one launch (the loss combination included) -- and, when the caller hands over
+        # the step's tail (`tail`), the keys' enqueue and the logged IoUs ride in the same launch (cp2_step_tail)
+        iou = iou_masked = None
+        if tail is None:
+            scal = ops.step_scalars(ins.loss, ins.cnt_gt, ext, den.sample_scal, q_pos, k_pos, lmbd_dense, qs[0], qs[1], qs[2], lneg_mean)
+        else:
+            enq = None
+            if tail.get("enqueue") is not None:
+                queue_ptr, gather = tail["enqueue"]
+                enq = (queue, (gather(k_pos) if gather is not None else k_pos).contiguous(), queue_ptr)
+            io = tail.get("iou")
+            scal, iou, iou_masked = ops.step_tail(ins.loss, ins.cnt_gt, ext, den.sample_scal, q_pos, k_pos, lmbd_dense, qs[0], qs[1],
+                                                  qs[2], lneg_mean, enqueue=enq,
+                                                  iou=None if io is None else (io[0], io[1], io[2], mask_a, mask_b))
         outs = (scal[S_LOSS], scal, k_pos, q_pos, den.sample_scal, extras[:, 0])
         if want_lneg:
             outs = outs + (ins.lneg,)
         if want_quart:
             outs = outs + (qs[0], qs[1], qs[2], lneg_mean)
+        if iou is not None:
+            outs = outs + (iou, iou_masked)
         ctx.mark_non_differentiable(*outs[1:])
         return outs
 
@@ -118,19 +134,23 @@ def cp2_loss_section(q_feat: torch.Tensor, k_feat: torch.Tensor, mask_a: torch.T
                      lmbd_dense: float = 0.2, include_background: bool = False, ids=None,
                      weights: Tuple[float, float, float] = (1.0, 1.0, 1.0), want_lneg: bool = False,
                      want_quartiles: bool = False, negative_type: int = 0, negative_scale: float = 2.0,
-                     k_row: Optional[torch.Tensor] = None) -> CP2LossOutputs:
+                     k_row: Optional[torch.Tensor] = None, tail: Optional[dict] = None) -> CP2LossOutputs:
     """q_feat / k_feat: encoder outputs [B,128,h,w] (NCHW or channels-last, fp32; no grad into k); mask_a / mask_b: [B,P]
     down-sampled foreground masks; queue [128,K].  k_row (int64 [B], optional): sample n's key features are row k_row[n]
     of k_feat -- the un-shuffle of builder.py:649 without a gather launch; None: k_feat is already in sample order.
     ids = (pixel_ids_a, pixel_ids_b, region_ids_a, region_ids_b) int64 [B,P] when the
-    correspondence weights are not all one (reference builder.py:1225-1243)."""
+    correspondence weights are not all one (reference builder.py:1225-1243).
+    tail (the training step): {"enqueue": (queue_ptr, gather_fn or None), "iou": (region_ids_a, region_ids_b [B,H,W], stride)}
+    -- either entry optional -- puts the enqueue of the keys (all ranks' keys through gather_fn; reference builder.py:1426,
+    :569-587) and the IoUs of the down-sampled id maps (:1204-1219) into the launch that forms the step's scalars; the
+    queue is then updated when this function returns, and the outputs carry `iou` / `iou_masked`."""
     if ids is not None and tuple(float(w) for w in weights) == (1.0, 1.0, 1.0):
         ids = None                                   # all weights one: the predicate is never needed
     if int(negative_type) not in (NEG_NONE, NEG_FIXED, NEG_AVERAGE, NEG_MEDIAN, NEG_HARD):
         raise ValueError(f"negative_type {negative_type!r}")
     cfg = (float(temp_global), float(temp_local), float(lmbd_dense), bool(include_background), ids,
            tuple(float(w) for w in weights), bool(want_lneg), bool(want_quartiles), (int(negative_type), float(negative_scale)),
-           k_row)
+           k_row, tail)
     outs = _CP2LossFn.apply(q_feat, k_feat.detach(), mask_a, mask_b, queue, cfg)
     loss, scal, k_pos, q_pos, sample, ins_pos = outs[:6]
     res = CP2LossOutputs(loss=loss, loss_instance=scal[S_LOSS_INS], loss_dense=scal[S_LOSS_DENSE], acc_dense=scal[S_ACC_DENSE],
@@ -142,4 +162,7 @@ def cp2_loss_section(q_feat: torch.Tensor, k_feat: torch.Tensor, mask_a: torch.T
         i += 1
     if want_quartiles:
         res.dense_pos_quartiles, res.dense_neg_quartiles, res.instance_neg_quartiles, res.instance_neg_mean = outs[i:i + 4]
+        i += 4
+    if tail is not None and tail.get("iou") is not None:
+        res.iou, res.iou_masked = outs[i:i + 2]
     return res

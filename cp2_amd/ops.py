@@ -565,6 +565,54 @@ def step_scalars(ins_loss, cnt_gt, extras, sample_scal, q_pos, k_pos, lmbd_dense
     return out
 
 
+def step_tail(ins_loss, cnt_gt, extras, sample_scal, q_pos, k_pos, lmbd_dense: float, dense_pos_q=None, dense_neg_q=None,
+              ins_neg_q=None, lneg_mean=None, enqueue=None, iou=None):
+    """step_scalars + enqueue + corr_iou_strided as ONE launch (cp2_step_tail).
+    enqueue: None or (queue [C,K], keys [n,C], ptr int64[1]); iou: None or (ids_a, ids_b [B,H,W] int64, stride, mask_a,
+    mask_b [B,P]).  Returns (scalars [24], iou [B] or None, iou_masked [B] or None)."""
+    lib = _lib.load()
+    B, C = q_pos.shape
+    dev = q_pos.device
+    out = torch.empty(STEP_SCALARS, dtype=torch.float32, device=dev)
+    queue = keys = ptr = ticket = None
+    n_keys = K = 0
+    if enqueue is not None:
+        queue, keys, ptr = enqueue
+        K, (n_keys, c2) = queue.shape[1], keys.shape
+        if c2 != C or queue.shape[0] != C or ptr.numel() != 1:
+            raise ValueError("step_tail: queue [C,K], keys [n,C] and a one-element pointer expected")
+        ticket = _enqueue_ticket(queue)
+    ids_a = ids_b = ma = mb = iou_o = ioum_o = None
+    H = W = stride = 0
+    if iou is not None:
+        ids_a, ids_b, stride, ma, mb = iou
+        _, H, W = ids_a.shape
+        P = ds_size(H, stride) * ds_size(W, stride)
+        if ma.shape[1] != P or mb.shape[1] != P:
+            raise ValueError(f"step_tail: masks must have {P} elements per sample")
+        iou_o = torch.empty(B, dtype=torch.float32, device=dev)
+        ioum_o = torch.empty(B, dtype=torch.float32, device=dev)
+    rc = lib.cp2_step_tail(_dev(ins_loss, "ins_loss", torch.float32), _dev(cnt_gt, "cnt_gt", torch.int32),
+                           _dev(extras, "extras", torch.float32), extras.shape[1], _dev(sample_scal, "sample_scal", torch.float32),
+                           _dev(q_pos, "q_pos", torch.float32), _dev(k_pos, "k_pos", torch.float32),
+                           _opt(dense_pos_q, "dense_pos_q", torch.float32), _opt(dense_neg_q, "dense_neg_q", torch.float32),
+                           _opt(ins_neg_q, "ins_neg_q", torch.float32), _opt(lneg_mean, "lneg_mean", torch.float32),
+                           float(lmbd_dense), out.data_ptr(), B, C,
+                           _opt(queue, "queue", torch.float32), _opt(keys, "keys", torch.float32), _opt(ptr, "queue_ptr", torch.int64),
+                           None if ticket is None else ticket.data_ptr(), n_keys, K,
+                           _opt(ids_a, "ids_a", torch.int64), _opt(ids_b, "ids_b", torch.int64), _opt(ma, "mask_a", torch.float32),
+                           _opt(mb, "mask_b", torch.float32), _opt(iou_o, "iou"), _opt(ioum_o, "iou_masked"), H, W, int(stride), _stream())
+    if rc and ticket is not None:
+        ticket.zero_()
+    _lib.check(rc, "cp2_step_tail")
+    return out, iou_o, ioum_o
+
+
+def tail_iou_supported(H: int, W: int, stride: int) -> bool:
+    """The IoU part of step_tail counts keys in an LDS hash table: at most 2047 down-sampled cells per map."""
+    return 2 * ds_size(H, stride) * ds_size(W, stride) + 1 <= 4096
+
+
 # ---------------------------------------------------------------- a10 / a16
 class RowKeyResult:
     __slots__ = ("loss", "lse", "loss_rows", "cnt_gt", "drows", "dE", "lnegT", "lneg", "ksplit")

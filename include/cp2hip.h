@@ -168,6 +168,17 @@ int cp2_step_scalars(const float* ins_loss, const int32_t* cnt_gt, const float* 
                      const float* q_pos, const float* k_pos, const float* dense_pos_quart, const float* dense_neg_quart,
                      const float* ins_neg_quart, const float* lneg_mean, float lmbd_dense, float* out, int B, int C,
                      void* stream);
+/* The tail of the step's loss section as ONE launch: cp2_step_scalars (arguments as above) + cp2_enqueue of `keys`
+ * [n_keys,C] into queue [C,K] (queue NULL: no enqueue) + cp2_corr_iou_strided of the full-resolution id maps [B,H,W]
+ * with the down-sampled masks [B,Hs*Ws] (ids_a NULL: no IoUs; at most 2047 down-sampled cells per map).  The three parts
+ * are independent workgroups of one kernel (none reads what another writes); each of the three single entry points
+ * launches the same kernel with only its own part.  builder.py:1431-1448,1553-1604 + :569-587 + :1204-1219. */
+int cp2_step_tail(const float* ins_loss, const int32_t* cnt_gt, const float* extras, int NE, const float* sample_scal,
+                  const float* q_pos, const float* k_pos, const float* dense_pos_quart, const float* dense_neg_quart,
+                  const float* ins_neg_quart, const float* lneg_mean, float lmbd_dense, float* out, int B, int C,
+                  float* queue, const float* keys, int64_t* queue_ptr, int32_t* ticket, int n_keys, int K,
+                  const int64_t* ids_a, const int64_t* ids_b, const float* mask_a, const float* mask_b, float* iou,
+                  float* iou_masked, int H, int W, int stride, void* stream);
 
 /* ---- a10 / a16: rows-vs-queue InfoNCE (f32 MFMA) ---------- builder.py:1395-1428 (instance),
  *                                                            :866-873,906-908,150-176 (DenseCL local)
