@@ -13,9 +13,11 @@ HBM, with the random parameters drawn on the host the way the reference's transf
 Pixel values.  Background views follow torchvision's PIL code path in Pillow's own integer / float arithmetic
 (csrc/photometric.hip; pinned against Pillow by tests/golden/make_augment_goldens.py): crop + antialiased bilinear resize,
 the four colour adjustments in their drawn order, grayscale, Gaussian blur, flip, ToTensor, RandomErasing.  Foreground
-views are cv2 / albumentations in the reference (loader.py:93-109), neither installed nor pinned: their crop is resampled
-with cv2.resize's geometry (half-pixel centres, no antialiasing) in fp32 and rounded to uint8 -- PARITY-UNPINNED -- and
-then go through the same Pillow-arithmetic colour stages (albumentations' own LUT arithmetic is unpinned as well) and
+views are cv2 / albumentations in the reference (loader.py:93-109), neither installed nor pinned: the crop of a uint8
+dataset is resampled in cv2.resize's INTER_LINEAR integer arithmetic as OpenCV's source publishes it (11-bit weights, int32
+horizontal pass, the vertical pass's shifts, the 2 x 2 area special case; oracle/augment_oracle.py cv2_resize_linear_u8) --
+restated from the dependency's source, PARITY-UNPINNED -- and then goes through the same Pillow-arithmetic colour stages
+(albumentations' ColorJitter rides on cv2's colour conversions and LUTs, which are not restated: unpinned as well) and
 Pillow's Gaussian blur, which IS what the reference calls for them (loader.py:136-152).
 """
 from __future__ import annotations

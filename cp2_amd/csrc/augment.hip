@@ -6,7 +6,10 @@
 //   main.py:204-225    background view: RandomResizedCrop + flip, then RandomErasing(p=1, value=0)
 // The random parameters (crop box, flip, erase box) are drawn on the host exactly as the transforms do
 // (cp2_amd/augment.py) and passed in a device table, so a CPU restatement can be compared bit for bit: the id maps and
-// the zero rectangle are integer / exact-zero work; the bilinear image is fp32 arithmetic in a fixed order (no FMA).
+// the zero rectangle are integer / exact-zero work; the bilinear image of an fp32 dataset is fp32 arithmetic in a fixed
+// order (no FMA); a uint8 dataset (what cv2.imread hands the reference) is resampled in cv2.resize's INTER_LINEAR integer
+// arithmetic -- 11-bit weights, int32 horizontal pass, the vertical pass's documented shifts, the 2 x 2 area special case --
+// restated from OpenCV's published source (cv2 is absent here: parity-unpinned, oracle/augment_oracle.py says how).
 // The whole dataset stays resident in HBM (uint8 or fp32); one thread makes one output pixel (3 channels + 2 ids).
 // HBM-bound, no MFMA: 12 B/pixel of image writes + 16 B/pixel of ids, source reads served mostly by L2.
 #include "common.hpp"
@@ -24,6 +27,20 @@ struct CropArgs {
 __device__ __forceinline__ float src_px(const CropArgs& a, int64_t plane, int y, int x) {
     const int64_t o = plane + (int64_t)y * a.Ws + x;
     return a.src_u8 ? (float)static_cast<const unsigned char*>(a.src)[o] / 255.0f : static_cast<const float*>(a.src)[o];
+}
+
+// cv2.resize INTER_LINEAR tap of destination index d (oracle/augment_oracle.py _cv2_linear_taps): left tap, right tap, weights
+__device__ __forceinline__ void cv2_tap(int d, int src_size, int dst_size, int& s0, int& s1, int& w0, int& w1) {
+    const double scale = (double)src_size / (double)dst_size;
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { s = 0; f = 0.f; }
+    if (s >= src_size - 1) { s = src_size - 1; f = 0.f; }
+    s0 = s;
+    s1 = min(s + 1, src_size - 1);
+    w0 = (int)rintf((1.0f - f) * 2048.0f);       // saturate_cast<short>(float): round half to even
+    w1 = (int)rintf(f * 2048.0f);
 }
 
 __global__ __launch_bounds__(256) void crop_resize_flip_kernel(CropArgs a) {
@@ -51,7 +68,33 @@ __global__ __launch_bounds__(256) void crop_resize_flip_kernel(CropArgs a) {
     if (a.out_pix) a.out_pix[o_id] = pid;
     // the region map goes through the same rescale_ids + INTER_NEAREST_EXACT round trip as the pixel ids (loader.py:75-83)
     if (a.out_reg) a.out_reg[o_id] = a.src_region ? a.src_region[((int64_t)n * a.Hs + ry) * a.Ws + rx] : pid;
-    // ---- image: bilinear with half-pixel centres, edges replicated; products and sums rounded one by one
+    if (a.src_u8) {
+        // ---- image of a uint8 dataset: cv2.resize(crop, INTER_LINEAR) in its fixed-point arithmetic, then ToTensor's / 255
+        const unsigned char* S = static_cast<const unsigned char*>(a.src);
+        uint32_t packed = 0;
+        int x0, x1, a0, a1, y0, y1, b0, b1;
+        cv2_tap(xr, cw, a.W, x0, x1, a0, a1);
+        cv2_tap(y, ch, a.H, y0, y1, b0, b1);
+        const bool area = ch == 2 * a.H && cw == 2 * a.W;           // exact 2 x 2 shrink: INTER_AREA's fast path
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const unsigned char* pl = S + (((int64_t)n * 3 + c) * a.Hs + top) * a.Ws + left;
+            int q;
+            if (area) {
+                const unsigned char* r0 = pl + (int64_t)(2 * y) * a.Ws + 2 * xr;
+                q = ((int)r0[0] + (int)r0[1] + (int)r0[a.Ws] + (int)r0[a.Ws + 1] + 2) >> 2;
+            } else {
+                const int r0 = (int)pl[(int64_t)y0 * a.Ws + x0] * a0 + (int)pl[(int64_t)y0 * a.Ws + x1] * a1;
+                const int r1 = (int)pl[(int64_t)y1 * a.Ws + x0] * a0 + (int)pl[(int64_t)y1 * a.Ws + x1] * a1;
+                q = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+            }
+            if (a.out_img) a.out_img[(((int64_t)b * 3 + c) * a.H + y) * a.W + x] = (float)q / 255.0f;
+            packed |= (uint32_t)(q & 255) << (8 * c);
+        }
+        if (a.out_rgbx) a.out_rgbx[o_id] = packed;
+        return;
+    }
+    // ---- image of an fp32 dataset: bilinear with half-pixel centres, edges replicated; products and sums rounded one by one
     const float fy = ((float)y + 0.5f) * ((float)ch / (float)a.H) - 0.5f;
     const float fx = ((float)xr + 0.5f) * ((float)cw / (float)a.W) - 0.5f;
     const float cy = fminf(fmaxf(fy, 0.0f), (float)(ch - 1)), cx = fminf(fmaxf(fx, 0.0f), (float)(cw - 1));
@@ -67,8 +110,7 @@ __global__ __launch_bounds__(256) void crop_resize_flip_kernel(CropArgs a) {
         const float r0 = p00 * (1.0f - wx) + p01 * wx, r1 = p10 * (1.0f - wx) + p11 * wx;
         const float v = r0 * (1.0f - wy) + r1 * wy;
         if (a.out_img) a.out_img[(((int64_t)b * 3 + c) * a.H + y) * a.W + x] = v;
-        // uint8 view for the photometric stages: value * 255 rounded half up (cv2.resize would hand albumentations a
-        // uint8 image here; its 11-bit fixed-point interpolation is not restated -- parity-unpinned)
+        // uint8 view for the photometric stages: value * 255 rounded half up
         const int q = (int)floorf(v * 255.0f + 0.5f);
         packed |= (uint32_t)(q < 0 ? 0 : (q > 255 ? 255 : q)) << (8 * c);
     }

@@ -89,6 +89,54 @@ def pil_crop_resize(img: np.ndarray, box, h: int, w: int) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------- Convert.c
+# ---- foreground views: cv2.resize(crop, (w, h), interpolation=cv2.INTER_LINEAR) on uint8   (reference loader.py:93-109:
+# albumentations' RandomResizedCrop calls it).  cv2 is a third-party dependency, absent from /root/reference, un-pinned in
+# its requirements.txt and NOT installed here: the arithmetic below is restated from OpenCV's published source
+# (modules/imgproc/src/resize.cpp, 4.x: resizeGeneric_ / HResizeLinear / VResizeLinear<uchar, int, short, ...>) and is
+# PARITY-UNPINNED -- no fixture and no live library can confirm it in this container:
+#   * destination pixel centre -> source coordinate (d + 0.5) * (src / dst) - 0.5 (evaluated in double, stored as float),
+#     left tap floor(f), fraction f - floor(f); a tap left of the image becomes tap 0 with fraction 0, a tap at or beyond
+#     the last pixel becomes the last pixel with fraction 0;
+#   * weights as 11-bit fixed point: saturate_cast<short>(w * 2048) = round-half-to-even of the float product;
+#   * horizontal pass in int32: S[x0] * a0 + S[x1] * a1;
+#   * vertical pass: (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+#   * an exact 2 x 2 shrink is served by INTER_AREA's fast path instead: (a + b + c + d + 2) >> 2.
+def _cv2_linear_taps(src_size: int, dst_size: int):
+    scale = float(src_size) / float(dst_size)
+    d = np.arange(dst_size, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = (f - s.astype(np.float32)).astype(np.float32)
+    low = s < 0
+    s[low], f[low] = 0, 0.0
+    high = s >= src_size - 1
+    s[high], f[high] = src_size - 1, 0.0
+    a0 = np.rint((np.float32(1.0) - f) * np.float32(2048.0)).astype(np.int64)      # cvRound: half to even
+    a1 = np.rint(f * np.float32(2048.0)).astype(np.int64)
+    return s, np.minimum(s + 1, src_size - 1), a0, a1
+
+
+def cv2_resize_linear_u8(img: np.ndarray, h: int, w: int) -> np.ndarray:
+    """img: (H, W, C) uint8 -> (h, w, C) uint8 as cv2.resize(img, (w, h), interpolation=cv2.INTER_LINEAR) (see above)."""
+    H, W = img.shape[:2]
+    src = img.astype(np.int64)
+    if H == 2 * h and W == 2 * w:
+        return ((src[0::2, 0::2] + src[0::2, 1::2] + src[1::2, 0::2] + src[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    x0, x1, a0, a1 = _cv2_linear_taps(W, w)
+    y0, y1, b0, b1 = _cv2_linear_taps(H, h)
+    rows = src[:, x0] * a0[None, :, None] + src[:, x1] * a1[None, :, None]            # (H, w, C) int
+    r0, r1 = rows[y0], rows[y1]
+    out = (((b0[:, None, None] * (r0 >> 4)) >> 16) + ((b1[:, None, None] * (r1 >> 4)) >> 16) + 2) >> 2
+    return out.astype(np.uint8)
+
+
+def foreground_crop_u8(src: np.ndarray, box, flip: bool, h: int, w: int) -> np.ndarray:
+    """src: (3, Hs, Ws) uint8; A.RandomResizedCrop (crop, cv2.resize INTER_LINEAR) then A.HorizontalFlip -> (h, w, 3) uint8."""
+    top, left, ch, cw = [int(v) for v in box]
+    out = cv2_resize_linear_u8(np.ascontiguousarray(src[:, top:top + ch, left:left + cw].transpose(1, 2, 0)), h, w)
+    return out[:, ::-1] if flip else out
+
+
 def rgb_to_l(img: np.ndarray) -> np.ndarray:
     """L24 / rgb2l: (R*19595 + G*38470 + B*7471 + 0x8000) >> 16."""
     r, g, b = (img[..., c].astype(np.int64) for c in range(3))

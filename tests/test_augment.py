@@ -77,6 +77,25 @@ def test_epoch_sampler_partitions_like_distributed_sampler():
     assert not np.array_equal(parts[0], A.EpochSampler(n, world, 0, 1024).indices(4))
 
 
+def test_cv2_linear_restatement_properties():
+    """oracle.augment_oracle.cv2_resize_linear_u8 (OpenCV's INTER_LINEAR on uint8, restated from its source: cv2 is absent,
+    so these are the properties the arithmetic must have, not a pin): same-size resize is the identity, constants survive,
+    an exact 2 x 2 shrink is the rounded block mean (INTER_AREA's fast path), a ramp stays monotone, borders replicate."""
+    from oracle import augment_oracle as AO
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    assert np.array_equal(AO.cv2_resize_linear_u8(img, 37, 53), img)
+    assert (AO.cv2_resize_linear_u8(np.full((30, 41, 3), 173, np.uint8), 64, 80) == 173).all()
+    big = rng.integers(0, 256, (48, 80, 3), dtype=np.uint8).astype(np.int64)
+    want = (big[0::2, 0::2] + big[0::2, 1::2] + big[1::2, 0::2] + big[1::2, 1::2] + 2) >> 2
+    assert np.array_equal(AO.cv2_resize_linear_u8(big.astype(np.uint8), 24, 40), want.astype(np.uint8))
+    ramp = np.tile(np.linspace(0, 255, 20).astype(np.uint8)[None, :, None], (5, 1, 3))
+    up = AO.cv2_resize_linear_u8(ramp, 5, 77).astype(int)
+    assert (np.diff(up[0, :, 0]) >= 0).all() and up[0, 0, 0] == 0 and up[0, -1, 0] == 255
+    f = AO.foreground_crop_u8(img.transpose(2, 0, 1), (2, 3, 20, 30), True, 16, 24)
+    assert np.array_equal(f, AO.foreground_crop_u8(img.transpose(2, 0, 1), (2, 3, 20, 30), False, 16, 24)[:, ::-1])
+
+
 # ------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("u8,stride", [(False, 1), (True, 1), (False, 2)])
@@ -100,6 +119,10 @@ def test_crop_resize_flip_and_erase_match_oracle_bit_for_bit(u8, stride):
     srcf = (src.astype(np.float32) / np.float32(255.0)) if u8 else src
     for b in range(B):
         want_img, want_pix, want_reg = O.crop_resize_flip(srcf[idx[b]], region[idx[b]], boxes[b], bool(flips[b]), H, W, stride)
+        if u8:      # a uint8 dataset is resampled as cv2.resize(INTER_LINEAR) does on uint8, then divided by 255 (ToTensor)
+            from oracle import augment_oracle as AO
+            want_img = (AO.foreground_crop_u8(src[idx[b]], boxes[b], bool(flips[b]), H, W).transpose(2, 0, 1).astype(np.float32)
+                        / np.float32(255.0))
         assert np.array_equal(pix[b].cpu().numpy(), want_pix), b
         assert np.array_equal(reg[b].cpu().numpy(), want_reg), b
         assert np.array_equal(img[b].cpu().numpy(), want_img), b                                  # same fp32 operations, same order

@@ -245,20 +245,24 @@ def test_kernels_vs_oracle_at_training_size():
 
 @pytest.mark.gpu
 def test_foreground_uint8_view_and_blur_radius_guard():
-    """The foreground crop's uint8 view (fp32 half-pixel bilinear rounded half up -- the oracle's stated rule; cv2's own
-    arithmetic is unpinned) and the argument checks of the blur entry."""
+    """The foreground crop's uint8 view = cv2.resize(crop, INTER_LINEAR) in its integer arithmetic as the oracle restates it
+    from OpenCV's source (11-bit weights, int32 horizontal pass, shifted vertical pass; an exact 2 x 2 shrink through the
+    area fast path) -- kernel == restatement bit for bit; cv2 itself is absent, so the restatement is parity-unpinned -- and
+    the argument checks of the blur entry."""
     from cp2_amd import _lib, ops
     rng = np.random.default_rng(2)
-    N, Hs, Ws, H, W, B = 3, 50, 61, 40, 44, 6
+    N, Hs, Ws, H, W, B = 3, 100, 120, 40, 44, 7
     src = rng.integers(0, 256, (N, 3, Hs, Ws), dtype=np.uint8)
     idx, boxes, flips = rng.integers(0, N, B), A.rrc_params(rng, B, Hs, Ws), rng.random(B) < 0.5
+    boxes[5] = (7, 9, 2 * H, 2 * W)                              # exact 2 x 2 shrink
+    boxes[6] = (0, 0, 13, 17)                                    # enlargement
     tab = torch.from_numpy(A.crop_table(idx, boxes, flips)).cuda()
     rgbx = torch.empty((B, H, W), dtype=torch.int32, device="cuda")
     img, pix, reg = ops.crop_resize_flip(torch.from_numpy(src).cuda(), None, tab, H, W, 1, want_f32=False, out_rgbx=rgbx)
     assert img is None
     for b in range(B):
-        want, want_pix, _ = O.crop_resize_flip(src[idx[b]].astype(np.float32) / np.float32(255.0), None, boxes[b], bool(flips[b]), H, W)
-        assert np.array_equal(_unpack(rgbx)[b], O.quantize_u8(want)), b
+        _, want_pix, _ = O.crop_resize_flip(src[idx[b]].astype(np.float32) / np.float32(255.0), None, boxes[b], bool(flips[b]), H, W)
+        assert np.array_equal(_unpack(rgbx)[b], P.foreground_crop_u8(src[idx[b]], boxes[b], bool(flips[b]), H, W)), b
         assert np.array_equal(pix[b].cpu().numpy(), want_pix)
     with pytest.raises(_lib.Cp2LibraryError):
         ops.blur_to_tensor(rgbx, torch.zeros((B, 4), dtype=torch.int32, device="cuda"), None, 99)

@@ -293,11 +293,14 @@ def test_key_weight_shadow_is_exact_and_used():
                 return i, name, mod, a, b
         return None
 
-    keep = (torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic)
+    keep = (torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic, Conv2d.gemm_1x1)
     try:
         for deterministic in (True, False):
             torch.backends.cudnn.deterministic = deterministic
             torch.backends.cudnn.benchmark = not deterministic
+            # with the image, the wide 1x1 stride-1 layers of a gradient-free forward run as hipBLASLt GEMMs (another kernel,
+            # another summation order than MIOpen's); the exact comparison is between the SAME MIOpen problems
+            Conv2d.gemm_1x1 = not deterministic
             _leaf_walk(model.encoder_k, x, True)                         # the first call of a configuration may run MIOpen's find
             y_img, leaves_img = _leaf_walk(model.encoder_k, x, True)
             y_again, leaves_again = _leaf_walk(model.encoder_k, x, True)
@@ -313,7 +316,7 @@ def test_key_weight_shadow_is_exact_and_used():
                 assert _bf16_ulps(a, b) <= 2, f"{name}: {_bf16_ulps(a, b)} bf16 ulps apart"
             assert (y_img.float() - y_cast.float()).abs().max().item() <= 2.0 ** -7 * y_cast.float().abs().max().item()
     finally:
-        torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = keep
+        torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic, Conv2d.gemm_1x1 = keep
 
 
 def test_key_forward_graph_equals_eager_key_forward():
