@@ -20,7 +20,15 @@ for W in cfg2 cfg5 cfg4; do
   # 2. matrix-pipe utilisation of the workload's MFMA kernels (cfg5: rows-vs-queue + positive selection; cfg4: the dense kernels)
   if [ $W != cfg2 ]; then
     timeout -k 10 500 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/pm_$W -o m --output-format csv -- python3 $R/bench.py --workload $W --steps 8 --warmup 6 --no-cpu-baseline > $O/bench_${W}_pmc.json 2> $O/bench_${W}_pmc.err || exit 1
-    cp /tmp/pm_$W/m_counter_collection.csv $O/r04_${W}_mfma_pmc_counters.csv
+    # keep the rows of the MFMA kernels only (the whole collection is ~17 MB of BN / convolution launches)
+    python3 - /tmp/pm_$W/m_counter_collection.csv $O/r04_${W}_mfma_pmc_counters.csv <<'PY'
+import csv, sys
+rows = list(csv.reader(open(sys.argv[1])))
+k = rows[0].index("Kernel_Name")
+out = csv.writer(open(sys.argv[2], "w", newline=""))
+out.writerow(rows[0])
+out.writerows(r for r in rows[1:] if any(s in r[k] for s in ("rowkey", "dense_fwd", "dense_bwd", "densecl_match")))
+PY
     python3 $R/tools/mfma_summarize.py /tmp/pm_$W/m_counter_collection.csv rowkey dense_fwd dense_bwd densecl_match > $O/r04_${W}_mfma_util.json
   fi
 done
