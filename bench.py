@@ -185,10 +185,9 @@ def count_flops_per_image(torch, model, batch, densecl=False):
     def fwd(enc, img):
         if not densecl:
             return enc(img).float().mean()
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            feat = enc.backbone(img)[3]
-        out = enc.neck(feat.float())                      # the DenseCL neck runs in fp32, as in the step
-        return out["x_global_proj"].mean() + out["x_local_proj"].mean()
+        with torch.autocast("cuda", dtype=torch.bfloat16):    # backbone and neck under autocast, as in the step
+            out = enc.neck(enc.backbone(img)[3])
+        return out["x_global_proj"].float().mean() + out["x_local_proj"].float().mean()
     try:
         with FlopCounterMode(display=False) as fc:
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=not densecl):
@@ -537,7 +536,7 @@ def main():
         method = "DenseCL"
         workload = (f"{label}: DenseCL (scripts/10-11-densecl.sh) ResNet-{depth} backbone OS{model.backbone_output_stride} + DenseCL neck, "
                     f"{hw}x{hw} crops, {P} pixels per image against queue2, queues 2 x {args.queue}, {common}"
-                    f"neck fp32, loss kernels split-bf16 / fp32 (logits within 3e-5), SGD(0.9, wd 1e-4), random-init weights")
+                    f"{'neck fp32, ' if amp is None or not model.neck_autocast else ''}loss kernels split-bf16 / fp32 (logits within 3e-5), SGD(0.9, wd 1e-4), random-init weights")
     else:
         method = "CP2"
         workload = (f"{label}: ResNet-{depth} + {head_name} head OS{model.output_stride}, {hw}x{hw} copy-paste pairs, "

@@ -85,7 +85,10 @@ class DenseCLNeck(nn.Module):
         super().__init__()
         self.avgpool_global = nn.AdaptiveAvgPool2d((1, 1))
         mlp = lambda a, b, c: nn.Sequential(nn.Linear(a, b), nn.ReLU(inplace=True), nn.Linear(b, c))  # noqa: E731
-        cnv = lambda a, b, c: nn.Sequential(nn.Conv2d(a, b, 1), nn.ReLU(inplace=True), nn.Conv2d(b, c, 1))  # noqa: E731
+        # encoder.Conv2d = nn.Conv2d (same parameter names) that reads the bf16 weight image under bf16 autocast and sends wide
+        # 1x1 layers through the GEMM / cp2_wgrad1x1 nodes, like the backbone's layers
+        from .encoder import Conv2d
+        cnv = lambda a, b, c: nn.Sequential(Conv2d(a, b, 1), nn.ReLU(inplace=True), Conv2d(b, c, 1))  # noqa: E731
         self.global_projector = mlp(in_channels, hid_channels, out_channels)
         self.global_predictor = mlp(out_channels, hid_channels, out_channels)
         self.with_pool = num_grid is not None
@@ -445,6 +448,7 @@ class MODEL(nn.Module):
         self._flat_q = self._flat_k = None
         self.log_quartiles = True        # per-step quartile statistics of the reference (builder.py:1298,1399-1406), sort-free
         self.key_weight_shadow = amp_dtype == torch.bfloat16   # EMA also emits bf16 key weights for the key encoder's convs
+        self.neck_autocast = True        # DenseCL neck in the encoders' autocast precision (False: fp32), see _neck
         self._flat_k_bf16 = None
         self._flat_q_bf16 = None         # bf16 image of the query weights, written by optim.FlatSGD (enable_query_shadow)
         self._q_shadow_version = None
@@ -730,6 +734,16 @@ class MODEL(nn.Module):
                 return enc(img)
         return enc(img)
 
+    def _neck(self, enc, feat):
+        """DenseCL neck (reference builder.py:179-274) on the last backbone map.  Under autocast it runs in the encoders'
+        precision like the decode head of the CP2 path (round 4; it ran in fp32 before: two 2048 -> 2048 1x1 convolutions
+        of 6272 pixels = 1.6 ms of fp32 MIOpen kernels per step at config 5); `neck_autocast = False` keeps it in fp32.  The
+        normalisation of its outputs and everything after is fp32 either way."""
+        if self.amp_dtype is not None and self.neck_autocast:
+            with torch.autocast("cuda", dtype=self.amp_dtype):
+                return enc.neck(feat)
+        return enc.neck(feat.float())
+
     # ------------------------------------------------------------------ CP2
     def forward_cp2(self, img_a, img_b, bg0, bg1, visualize, step, new_epoch, pixel_ids_a, pixel_ids_b,
                     region_ids_a, region_ids_b, idx_shuffle=None):
@@ -872,14 +886,14 @@ class MODEL(nn.Module):
 
         def query_features(img):
             feat = self._encode(self.encoder_q.backbone, img)[3]         # bf16 channels-last under autocast, else fp32
-            out = self.encoder_q.neck(feat.float())
+            out = self._neck(self.encoder_q, feat)
             local = out["x_local_pred"] if self.use_predictor else out["x_local_proj"]
             glob = out["x_global_pred"] if self.use_predictor else out["x_global_proj"]
             if self.use_avgpool_global:
                 glob = out["x_avgpool_local_pred"] if self.use_predictor else out["x_avgpool_local_proj"]
             # the backbone map goes to cp2_densecl_match as it is: only its arg-max is used (no gradient, reference
             # builder.py:818-821), and a positive factor per query pixel cannot change an arg-max -- no normalised copy
-            return feat.detach(), F.normalize(local.flatten(2), dim=1), F.normalize(glob, dim=1)
+            return feat.detach(), F.normalize(local.flatten(2).float(), dim=1), F.normalize(glob.float(), dim=1)
 
         key_pass = [0]
 
@@ -893,10 +907,10 @@ class MODEL(nn.Module):
 
             def run(x):
                 feat = self._encode(self.encoder_k.backbone, x)[3]
-                out = self.encoder_k.neck(feat.float())
+                out = self._neck(self.encoder_k, feat)
                 glob = out["x_avgpool_local_proj"] if self.use_avgpool_global else out["x_global_proj"]
-                return (feat, F.normalize(out["x_local_proj"].flatten(2), dim=1), F.normalize(glob, dim=1),
-                        F.normalize(out["x_avgpool_local_proj"], dim=1))
+                return (feat, F.normalize(out["x_local_proj"].flatten(2).float(), dim=1), F.normalize(glob.float(), dim=1),
+                        F.normalize(out["x_avgpool_local_proj"].float(), dim=1))
             # backbone + neck of the key side as one hipGraph replay per pass (the eager form costs ~2.5 ms of host time per
             # step: cfg5 measured host-bound at 17.1 ms); the two passes of the symmetric loss keep separate output buffers
             feat, local, glob, pooled = self._key_forward(f"densecl{key_pass[0]}", run, img)

@@ -148,6 +148,23 @@ __global__ __launch_bounds__(256, 2) void rowkey_bf16x3_dma_kernel(RowKeyArgs a,
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) o2[ks] = sbase + (unsigned)(r * 64 + (((2 * ks + h) ^ ((r >> 2) & 3)) * 16));
 
+    // ---- raw logits for the score statistics, row-major [row][key] (ln_sk == 1): the accumulator holds KEYS along the
+    // registers and ROWS along the lanes, so a direct store is 64 four-byte requests to 32 different rows per instruction
+    // -- with two workgroups per CU the texture addresser, not the matrix pipe, then bounds the launch (round 4: 370 us
+    // per 1568 x 65536 chunk against 150 us without the logits).  Each wave turns its 32 x 32 tile through 4 KB of LDS of
+    // its own (behind the two DMA buffers) and writes eight whole 128-byte row segments per instruction.
+    const bool ln_vec = __builtin_amdgcn_readfirstlane(
+        (a.lnegT != nullptr && a.ln_sk == 1 && (a.ln_sr & 3) == 0 && (((size_t)a.lnegT) & 15) == 0 && (k_begin & 3) == 0) ? 1 : 0);
+    const unsigned tbase = sbase + D_LDS + wid * 4096;
+    unsigned tw[4], tr[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        tw[g] = tbase + (unsigned)(r * 128 + (((2 * g + h) ^ (r & 7)) * 16));                 // keys 8g + 4h .. +3 of row r
+        const int rr = 8 * g + (lane >> 3);
+        tr[g] = tbase + (unsigned)(rr * 128 + (((lane & 7) ^ (rr & 7)) * 16));                // keys 4 (lane & 7) .. +3 of row rr
+    }
+    const int wave_row0 = (blockIdx.x * 4 + wid) * 32;
+
     float m_run = -INFINITY, s_run = 0.f;
     int cnt = 0;
     f32x16 U[4];
@@ -170,13 +187,39 @@ __global__ __launch_bounds__(256, 2) void rowkey_bf16x3_dma_kernel(RowKeyArgs a,
             acc = p1_step<BUF, 6>(acc, xh, xl, yh, yl, o1, bqh, bql);
             acc = p1_step<BUF, 7>(acc, yh, yl, xh, xl, o1, bqh, bql);
         }
+        if (ln_vec) {
+            f32x4 tv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 w4 = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                asm volatile("ds_write_b128 %0, %1" :: "v"(tw[g]), "v"(w4));
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) asm volatile("ds_read_b128 %0, %1" : "=v"(tv[g]) : "v"(tr[g]));   // same wave: LDS keeps the order
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]));
+            const int key = k0 + 4 * (lane & 7);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int grow = wave_row0 + 8 * g + (lane >> 3);
+                if (grow < a.R) {
+                    float* dst = a.lnegT + (int64_t)grow * a.ln_sr + key;
+                    if (key + 3 < k_end) {
+                        *reinterpret_cast<f32x4*>(dst) = tv[g];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (key + j < k_end) dst[j] = tv[g][j];
+                    }
+                }
+            }
+        }
         float sv[16];
         float tmax = -INFINITY;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int key = k0 + rho(reg, h);
             const bool valid = key < k_end;
-            if (a.lnegT && valid && row_ok) a.lnegT[(int64_t)key * a.ln_sk + (int64_t)row * a.ln_sr] = acc[reg];
+            if (!ln_vec && a.lnegT && valid && row_ok) a.lnegT[(int64_t)key * a.ln_sk + (int64_t)row * a.ln_sr] = acc[reg];
             sv[reg] = valid ? acc[reg] * a.inv_t : -INFINITY;
             tmax = fmaxf(tmax, sv[reg]);
             cnt += (sv[reg] > pos_s) ? 1 : 0;
@@ -260,8 +303,10 @@ __global__ __launch_bounds__(256, 2) void rowkey_bf16x3_dma_kernel(RowKeyArgs a,
 
 int rowkey_bf16x3_dma_launch(const RowKeyArgs& a, const void* ksplit, dim3 grid, bool with_u, hipStream_t stream) {
     auto kfn = with_u ? rowkey_bf16x3_dma_kernel<true> : rowkey_bf16x3_dma_kernel<false>;
-    hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, D_LDS);
+    // 4 KB per wave more when the launch also writes row-major logits (the in-LDS turn of the tiles): 2 x 80 KB = the CU's LDS
+    const int lds = D_LDS + ((a.lnegT != nullptr && a.ln_sk == 1) ? 4 * 4096 : 0);
+    hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, D_LDS + 4 * 4096);
     if (e_ != hipSuccess) return (int)e_;
-    CP2_LAUNCH_PROFILED(kfn, grid, dim3(256), D_LDS, stream, a, static_cast<const __bf16*>(ksplit));
+    CP2_LAUNCH_PROFILED(kfn, grid, dim3(256), lds, stream, a, static_cast<const __bf16*>(ksplit));
     return cp2_launch_status();
 }

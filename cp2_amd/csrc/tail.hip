@@ -159,8 +159,11 @@ __device__ __forceinline__ void enqueue_body(const EnqueueArgs& a, int b) {
 }
 
 // ---- part 2: a3-a5, IoU of two id maps by counting keys in an LDS hash table -- tools/correlation_mapping.py:103-138
-// The same counts without a sort, for maps of up to 2047 cells per side (the training shapes: P = 196 ... 1024): the
-// 2P+1 keys go into an open-addressing table in LDS (key bits + multiplicity per slot, load factor <= 1/2);
+// The same counts without a sort, for maps of up to 8191 cells per side (the training shapes: P = 196 ... 4096): the
+// 2P+1 keys go into an open-addressing table in LDS, load factor <= 1/2.  A slot is the key's bit pattern; "hit at least
+// twice" is one bit per slot in a bitmap behind the table: 4 bytes + 1 bit per slot, 66 KB for config 4's 4096-cell maps
+// (round 4; with a 4-byte count per slot the table stopped at 2047 cells and config 4 fell back to the 204 us
+// bitonic-sort launch);
 //   union = #occupied slots - 1 (the zero key is always present),  intersection = #slots of a non-zero key hit >= 2 times.
 // The bitonic network above needs 45 barrier stages for 512 keys (16-18 us per launch, latency); this form needs two.
 // Integer counting only: bit-equal to the sorted form (and to the reference's torch.unique arithmetic) by construction.
@@ -171,7 +174,7 @@ struct IouArgs {
     int B;                                       // 2 B workgroups (0: part switched off)
 };
 
-__device__ __forceinline__ void corr_iou_hash_body(const IouArgs& a, int b, unsigned* tab /* dynamic LDS: [T] key bits | [T] multiplicities */) {
+__device__ __forceinline__ void corr_iou_hash_body(const IouArgs& a, int b, unsigned* tab /* dynamic LDS: [T] key bits | [T / 32] twice bits */) {
     __shared__ int red[2][4];
     constexpr unsigned kEmpty = 0xFFFFFFFFu;                             // a NaN pattern: never a key
     const int64_t* __restrict__ ids_a = a.ids_a;
@@ -184,8 +187,9 @@ __device__ __forceinline__ void corr_iou_hash_body(const IouArgs& a, int b, unsi
     float* out = masked ? a.iou_masked : a.iou;
     if (!out) return;
     unsigned* keys = tab;
-    unsigned* cnt = tab + T;
-    for (int i = threadIdx.x; i < T; i += 256) { keys[i] = kEmpty; cnt[i] = 0; }
+    unsigned* twice = tab + T;
+    for (int i = threadIdx.x; i < T; i += 256) keys[i] = kEmpty;
+    for (int i = threadIdx.x; i < T / 32; i += 256) twice[i] = 0u;
     __syncthreads();
     auto at = [&](int p) -> int64_t {
         if (stride <= 0) return (int64_t)n * P + p;
@@ -209,7 +213,8 @@ __device__ __forceinline__ void corr_iou_hash_body(const IouArgs& a, int b, unsi
         unsigned slot = (bits * 2654435761u) >> (32 - shift);
         for (int probe = 0; probe < T; ++probe) {
             const unsigned prev = atomicCAS(&keys[slot], kEmpty, bits);
-            if (prev == kEmpty || prev == bits) { atomicAdd(&cnt[slot], 1u); break; }
+            if (prev == kEmpty) break;                                  // first occurrence
+            if (prev == bits) { atomicOr(&twice[slot >> 5], 1u << (slot & 31)); break; }
             slot = (slot + 1) & (unsigned)(T - 1);
         }
     }
@@ -219,7 +224,7 @@ __device__ __forceinline__ void corr_iou_hash_body(const IouArgs& a, int b, unsi
         const unsigned k = keys[i];
         if (k != kEmpty) {
             ++uniq;
-            if (k != 0u && cnt[i] >= 2u) ++inter;
+            if (k != 0u && ((twice[i >> 5] >> (i & 31)) & 1u)) ++inter;
         }
     }
     uniq = wave_sum_i(uniq);
@@ -272,11 +277,12 @@ static int tail_fill_enqueue(TailArgs& t, float* queue, const float* keys, int64
     return CP2_OK;
 }
 
-// hash-count form only (maps of at most 2047 cells: table of 2 * N2 slots, <= 64 KB); *lds = the dynamic LDS it needs
+// hash-count form only (maps of at most 8191 cells: table of 2 * N2 four-byte slots + its bitmap, <= 132 KB beside the
+// kernel's static 37 KB... so N2 <= 16384: 66 KB); *lds = the dynamic LDS it needs
 int cp2_tail_iou_table(int P) {
     int N2 = 64;
     while (N2 < 2 * P + 1) N2 <<= 1;
-    return N2 <= 4096 ? 2 * N2 : 0;
+    return N2 <= 16384 ? 2 * N2 : 0;
 }
 
 static int tail_fill_iou(TailArgs& t, size_t* lds, const int64_t* ids_a, const int64_t* ids_b, const float* mask_a, const float* mask_b,
@@ -288,7 +294,7 @@ static int tail_fill_iou(TailArgs& t, size_t* lds, const int64_t* ids_a, const i
     const int T = cp2_tail_iou_table(P);
     if (T == 0) return CP2_ERR_UNSUPPORTED;
     t.iou = IouArgs{ids_a, ids_b, mask_a, mask_b, iou, iou_masked, P, T, H, W, stride, Ws, B};
-    *lds = (size_t)2 * T * sizeof(unsigned);
+    *lds = (size_t)(T + T / 32) * sizeof(unsigned);
     return CP2_OK;
 }
 

@@ -9,6 +9,7 @@ the shared plain-torch encoder definition.  Only bench.py's `cpu_baseline` leg a
 from __future__ import annotations
 
 import copy
+import sys
 import time
 
 import torch
@@ -136,19 +137,25 @@ class CpuDenseCLStep:
 
 
 def time_cpu_baseline(cfg, make_batch, b, h, w, K, steps=2, warmup=1, threads=None, densecl=False, output_stride=16,
-                      temp_local=1.0, lmbd_dense=0.2):
+                      temp_local=1.0, lmbd_dense=0.2, progress=True):
     """images/sec of the CPU port on `threads` host threads (default: all)."""
     if threads:
         torch.set_num_threads(threads)
     runner = CpuDenseCLStep(cfg, K=K) if densecl else CpuCP2Step(cfg, K=K, output_stride=output_stride, temp_local=temp_local,
                                                                  lmbd_dense=lmbd_dense)
     batches = [{k: v.cpu() for k, v in make_batch(b, h, w, "cpu", seed=100 + i).items()} for i in range(warmup + steps)]
+    def note(what):                                      # one line per CPU step: a config-4 step takes a minute
+        if progress:
+            print(f"[cpu baseline] {what}", file=sys.stderr, flush=True)
+    note(f"{warmup} warm-up + {steps} timed steps of {b} images on {torch.get_num_threads()} threads")
     for i in range(warmup):
         runner.step(batches[i])
+        note(f"warm-up step {i + 1} done")
     runner.split = {}
     t0 = time.perf_counter()
     for i in range(warmup, warmup + steps):
         runner.step(batches[i])
+        note(f"timed step {i - warmup + 1} of {steps} done, {time.perf_counter() - t0:.1f} s")
     dt = time.perf_counter() - t0
     time_cpu_baseline.last_split_ms = {k: round(1e3 * v / steps, 1) for k, v in runner.split.items()}   # per step
     return b * steps / dt, torch.get_num_threads(), dt

@@ -442,6 +442,32 @@ def test_rowkey_bf16x3_vs_oracle(R_rows, K):
     assert torch.equal(got.cnt_gt, exact.cnt_gt) or (got.cnt_gt - exact.cnt_gt).abs().max() <= 2
 
 
+@pytest.mark.parametrize("R_rows,K,grad,shift", [(640, 8192, True, 0), (200, 1008, True, 0), (75, 2064, False, 0), (333, 1040, False, 1)])
+def test_rowkey_bf16x3_row_major_logits_equal_the_key_major_ones(R_rows, K, grad, shift):
+    """The row-major logits of the split-bf16 kernel (what the DenseCL score statistics read, builder.py:875-886) leave the
+    launch through an in-LDS turn of every 32 x 32 tile (round 4; whole 128-byte row segments per store instruction instead
+    of 64 four-byte requests).  They are the same accumulator registers as the key-major output: bit-equal, for ragged row
+    counts, a last tile of 16 keys, with and without the gradient product, and through the scalar path when the buffer is
+    not 16-byte aligned (`shift`); everything else the call returns is unchanged by the layout."""
+    gen = torch.Generator().manual_seed(R_rows + K)
+    C, T = 128, 0.2
+    rows = torch.nn.functional.normalize(torch.randn(R_rows, C, generator=gen), dim=1).to(DEV)
+    queue = torch.nn.functional.normalize(torch.randn(C, K, generator=gen), dim=0).to(DEV)
+    pos = (torch.rand(R_rows, 1, generator=gen) * 2 - 1).to(DEV)
+    gs = 1.0 / R_rows if grad else None
+    a = ops.rowkey_infonce(rows, (1, C, 0, 1), R_rows, queue, pos, T, grad_scale=gs, want_lneg=True, precision="bf16x3")
+    buf = torch.full((R_rows * K + 8,), float("nan"), device=DEV)
+    b = ops.rowkey_infonce(rows, (1, C, 0, 1), R_rows, queue, pos, T, grad_scale=gs, want_lneg=True, precision="bf16x3",
+                           lneg_row_major=True, lneg_out=buf[shift:shift + R_rows * K])
+    assert a.lnegT.shape == (K, R_rows) and b.lneg.shape == (R_rows, K)
+    assert torch.equal(a.lnegT.t(), b.lneg)
+    assert torch.isnan(buf[:shift]).all() and torch.isnan(buf[shift + R_rows * K:]).all()      # nothing outside the R x K block
+    assert torch.equal(a.loss_rows, b.loss_rows) and torch.equal(a.cnt_gt, b.cnt_gt)
+    if grad:
+        assert torch.equal(a.drows, b.drows) and torch.equal(a.dE, b.dE)
+    assert_close(b.lneg, rows @ queue, 3e-5, what="raw logits")
+
+
 @pytest.mark.parametrize("name", ["densecl_b2_128_k64", "densecl_b2_96_k64_coord"])
 def test_densecl_local_positives_and_losses_golden(golden_dir, name):
     """T18 + T19 of forward_densecl on the reference's recorded tensors (builder.py:808-910, :760-772)."""

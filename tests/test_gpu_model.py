@@ -98,6 +98,30 @@ def test_densecl_forward_backward_runs_and_advances_both_queues():
     assert abs(0.5 * logs["train/loss_ins_step"] + 0.5 * logs["train/loss_dense_step"] - logs["train/loss_step"]) < 1e-5
 
 
+def test_densecl_neck_under_autocast_stays_close_to_the_fp32_neck():
+    """Round 4: the DenseCL neck (builder.py:179-274) runs in the encoders' autocast precision (`MODEL.neck_autocast`), its
+    two 1x1 layers through encoder.Conv2d (bf16 weight image, cp2_wgrad1x1).  Same weights, same batch: the loss stays within
+    2 % of the fp32-neck step's, every neck parameter the flags select receives a finite gradient of the fp32-neck step's size."""
+    out = {}
+    for neck_amp in (True, False):
+        model = small_model(K=512, pretrain_type=PretrainType.DENSECL, cfg_name="config_moco.py", amp_dtype=torch.bfloat16,
+                            channels_last=True)
+        model.neck_autocast = neck_amp
+        model.encoder_q.to(memory_format=torch.channels_last)
+        model.encoder_k.to(memory_format=torch.channels_last)
+        batch = synthetic.make_batch(4, 64, 64, DEV, seed=5)
+        loss = model(visualize=False, step=0, new_epoch=False, idx_shuffle=torch.arange(4, device=DEV), **batch)
+        loss.backward()
+        neck = model.encoder_q.neck
+        out[neck_amp] = (float(loss), [p.grad.clone() for p in list(neck.local_projector.parameters()) + list(neck.global_projector.parameters())])
+        if neck_amp:
+            assert neck.local_projector[0].shadow_weight is not None and neck.local_projector[0].shadow_weight.dtype == torch.bfloat16
+    assert abs(out[True][0] - out[False][0]) <= 0.02 * abs(out[False][0]), (out[True][0], out[False][0])
+    for ga, gf in zip(out[True][1], out[False][1]):
+        assert torch.isfinite(ga).all()
+        assert (ga - gf).norm() <= 0.1 * gf.norm() + 1e-6, (float((ga - gf).norm()), float(gf.norm()))
+
+
 @pytest.mark.parametrize("case", [
     dict(ptype=PretrainType.DENSECL, flags={}, step=0),
     dict(ptype=PretrainType.PROPOSED_V2, flags=dict(use_symmetrical_loss=True, lmbd_coordinate=0.3), step=0),

@@ -19,7 +19,10 @@ for W in cfg2 cfg5 cfg4; do
   python3 $R/tools/kstats.py /tmp/pk_$W/b_kernel_trace.csv $LOSSK > $O/r04_bench_${W}_loss_kernels.txt
   # 2. matrix-pipe utilisation of the workload's MFMA kernels (cfg5: rows-vs-queue + positive selection; cfg4: the dense kernels)
   if [ $W != cfg2 ]; then
-    timeout -k 10 500 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/pm_$W -o m --output-format csv -- python3 $R/bench.py --workload $W --steps 8 --warmup 6 --no-cpu-baseline > $O/bench_${W}_pmc.json 2> $O/bench_${W}_pmc.err || exit 1
+    # (config 4 with fewer steps: the first attempt, 8 + 6 steps of ~1800 launches, died at dispatch 35216 with
+    # HSA_STATUS_ERROR_INVALID_PACKET_FORMAT under counter collection; the 14-step config-5 run, 19400 dispatches, is fine)
+    PS=8; PW=6; [ $W = cfg4 ] && PS=2 && PW=2
+    timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/pm_$W -o m --output-format csv -- python3 $R/bench.py --workload $W --steps $PS --warmup $PW --no-cpu-baseline > $O/bench_${W}_pmc.json 2> $O/bench_${W}_pmc.err || exit 1
     # keep the rows of the MFMA kernels only (the whole collection is ~17 MB of BN / convolution launches)
     python3 - /tmp/pm_$W/m_counter_collection.csv $O/r04_${W}_mfma_pmc_counters.csv <<'PY'
 import csv, sys
