@@ -20,6 +20,7 @@
 //                builder.py:1289-1292,1392,1431-1437 (column-wise log-softmax, dim=1)
 //   dense_bwd    owners = query pixels x, others = key pixels y: d loss / d q_dense
 #include "infonce_common.hpp"
+#include "rowkey_small_fin.hpp"
 
 // LDS tile T[c][j], j < KT, row pitch KT+1 floats (odd pitch: both the row read of
 // product 1 and the column read of product 2 are bank-conflict free).  The fill is split
@@ -733,16 +734,18 @@ __global__ __launch_bounds__(DNT, 2) void dense_fwd_kernel(DenseArgs a) {
 // One workgroup per sample folds the S partial column statistics of its own key pixels (splits cover increasing x ranges,
 // so "first maximum" -- torch.argmax's tie rule -- = strictly-greater replacement in split order), stores the merged
 // per-key values the backward and the callers read, and finishes the sample's scalars from them.
-__global__ __launch_bounds__(256) void dense_post_kernel(DenseArgs a, float* __restrict__ sample_scal, int64_t BP) {
-    __shared__ float red[6][4];
-    __shared__ float bv[4];
-    __shared__ int bi[4];
-    const int n = blockIdx.x, P = a.P, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+template <int NT>
+__device__ __forceinline__ void dense_post_body(const DenseArgs& a, float* __restrict__ sample_scal, int64_t BP, int n) {
+    constexpr int NW = NT / 64;
+    __shared__ float red[6][NW];
+    __shared__ float bv[NW];
+    __shared__ int bi[NW];
+    const int P = a.P, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int S = a.splits;
     const int64_t arr = (int64_t)S * BP;
     float sa = 0.f, sb = 0.f, t_lse = 0.f, t_a = 0.f, t_pos = 0.f, t_all = 0.f, best = -INFINITY;
     int64_t best_flat = 0;
-    for (int y = tid; y < P; y += 256) {
+    for (int y = tid; y < P; y += NT) {
         const int64_t o = (int64_t)n * P + y;
         float lse, ca, pos, all, cmax;
         int ax;
@@ -791,10 +794,17 @@ __global__ __launch_bounds__(256) void dense_post_kernel(DenseArgs a, float* __r
     __syncthreads();
     if (tid == 0) {
         float t[6];
-        for (int j = 0; j < 6; ++j) t[j] = red[j][0] + red[j][1] + red[j][2] + red[j][3];
+        for (int j = 0; j < 6; ++j) {
+            // pairwise over the waves: with 4 waves this is ((w0 + w1) + w2) + w3 as before; a 16-wave workgroup sums its
+            // own 16 partials in the same left-to-right order (the two workgroup sizes differ in the last bits: each is
+            // deterministic, and the step uses one of them throughout)
+            float acc = red[j][0];
+            for (int i = 1; i < NW; ++i) acc += red[j][i];
+            t[j] = acc;
+        }
         float bb = bv[0];
         int bf = bi[0];
-        for (int j = 1; j < 4; ++j)
+        for (int j = 1; j < NW; ++j)
             if (bv[j] > bb || (bv[j] == bb && bi[j] < bf)) { bb = bv[j]; bf = bi[j]; }
         const float Sa = t[0], Sb = t[1], npos = Sa * Sb;
         float* o = sample_scal + (int64_t)n * 8;
@@ -807,6 +817,19 @@ __global__ __launch_bounds__(256) void dense_post_kernel(DenseArgs a, float* __r
         o[6] = 0.f;
         o[7] = 0.f;
     }
+}
+
+__global__ __launch_bounds__(256) void dense_post_kernel(DenseArgs a, float* __restrict__ sample_scal, int64_t BP) {
+    dense_post_body<256>(a, sample_scal, BP, (int)blockIdx.x);
+}
+
+// The instance loss's finalize (rowkey_small_finalize_body: CH / FS2_CPB workgroups of 1024 threads) and the dense loss's
+// post-pass (one workgroup per sample) in ONE launch: neither reads what the other writes, both follow their producer
+// kernels in stream order (round 4: loss section 11 -> 10 launches).
+__global__ __launch_bounds__(1024) void loss_post_kernel(RowKeyFinArgs fa, float* __restrict__ loss_mean, DenseArgs da,
+                                                         float* __restrict__ sample_scal, int64_t BP, int nfin) {
+    if ((int)blockIdx.x < nfin) { rowkey_small_finalize_body(fa, loss_mean, (int)blockIdx.x); return; }
+    dense_post_body<1024>(da, sample_scal, BP, (int)blockIdx.x - nfin);
 }
 
 // owners = query pixels x (lane), others = key pixels y (LDS tile).
@@ -919,7 +942,7 @@ CP2_API int cp2_dense_infonce_fwd(const float* q_dense, const float* k_dense, co
                                   const float* negative_center, int B, int C, int P, void* stream) {
     int rc = dense_check(q_dense, k_dense, mask_a, mask_b, pix_a, pix_b, reg_a, reg_b, B, C, P, temperature);
     if (rc) return rc;
-    if (!lse || !colsum_a || !possum || !allsum || !colmax || !argx || !sample_scal) return CP2_ERR_NULL;
+    if (!lse || !colsum_a || !possum || !allsum || !colmax || !argx) return CP2_ERR_NULL;   // sample_scal NULL: post-pass deferred to cp2_loss_post
     const int S = split_ws ? cp2_dense_num_splits(B, P) : 1;
     DenseArgs a{q_dense, k_dense, mask_a, mask_b, pix_a, pix_b, reg_a, reg_b, w_pixel, w_region, w_not,
                 1.0f / temperature, P, lse, colsum_a, possum, allsum, colmax, argx, logits_out, nullptr, 0.f, nullptr,
@@ -932,9 +955,37 @@ CP2_API int cp2_dense_infonce_fwd(const float* q_dense, const float* k_dense, co
     } else if (pix_a) CP2_LAUNCH_PROFILED((dense_fwd_kernel<true, false>), grid, dim3(DNT), lds, cp2_stream(stream), a);
     else CP2_LAUNCH_PROFILED((dense_fwd_kernel<false, false>), grid, dim3(DNT), lds, cp2_stream(stream), a);
     rc = cp2_launch_status();
-    if (rc) return rc;
+    if (rc || !sample_scal) return rc;
     hipLaunchKernelGGL(dense_post_kernel, dim3(B), dim3(256), 0, cp2_stream(stream), a, sample_scal, (int64_t)B * P);
     return cp2_launch_status();                            // the batch means are formed by cp2_step_scalars
+}
+
+// Finalize of cp2_rowkey_infonce_fwd's partials (the small-R form: R <= 32, nsplit >= 16 -- the instance loss) and the
+// post-pass of a cp2_dense_infonce_fwd call that was given sample_scal = NULL, in one launch.  Arguments as in
+// cp2_rowkey_infonce_finalize, then the dense call's own output arrays, split workspace (NULL: no split) and masks.
+CP2_API int cp2_loss_post(const float* part_m, const float* part_s, const int32_t* part_cnt, const float* part_U, int nsplit,
+                          const float* extras, int NE, float temperature, float grad_scale, int R, int RP, int64_t d_sn,
+                          int64_t d_sx, int64_t d_sc, float* lse, float* loss_rows, int32_t* cnt_gt, float* drows, float* dE,
+                          float* loss_mean, const float* mask_a, const float* mask_b, float* d_lse, float* colsum_a,
+                          float* possum, float* allsum, float* colmax, int32_t* argx, float* sample_scal, float* split_ws,
+                          int B, int C, int P, void* stream) {
+    if (!part_m || !part_s || !part_cnt || !lse || !loss_rows || !cnt_gt) return CP2_ERR_NULL;
+    if (drows && !part_U) return CP2_ERR_NULL;
+    if (NE > 0 && !extras) return CP2_ERR_NULL;
+    if (!mask_a || !mask_b || !d_lse || !colsum_a || !possum || !allsum || !colmax || !argx || !sample_scal) return CP2_ERR_NULL;
+    if (R <= 0 || RP <= 0 || nsplit <= 0 || NE < 0 || NE > 4 || !(temperature > 0.f) || B <= 0 || P <= 0) return CP2_ERR_SHAPE;
+    if (C != CH || R > 32 || nsplit < 16) return CP2_ERR_UNSUPPORTED;       // other row counts: the two separate entry points
+    RowKeyFinArgs fa{part_m, part_s, part_cnt, part_U, nsplit, extras, NE, 1.0f / temperature, grad_scale,
+                     R, RP, d_sn, d_sx, d_sc, lse, loss_rows, cnt_gt, drows, dE};
+    DenseArgs da{};
+    da.mask_a = mask_a; da.mask_b = mask_b; da.P = P;
+    da.lse = d_lse; da.colsum_a = colsum_a; da.possum = possum; da.allsum = allsum; da.colmax = colmax; da.argx = argx;
+    da.splits = split_ws ? cp2_dense_num_splits(B, P) : 1;
+    da.part = split_ws;
+    const int nfin = CH / FS2_CPB;
+    hipLaunchKernelGGL(loss_post_kernel, dim3(nfin + B), dim3(1024), 0, cp2_stream(stream), fa, loss_mean, da, sample_scal,
+                       (int64_t)B * P, nfin);
+    return cp2_launch_status();
 }
 
 CP2_API int cp2_dense_infonce_bwd(const float* q_dense, const float* k_dense, const float* mask_a,

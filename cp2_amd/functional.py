@@ -62,8 +62,10 @@ class _CP2LossFn(torch.autograd.Function):
         q_pos, q_neg, q_norms, k_pos, k_neg, extras = ops.pool_finalize(q_part, k_part, P)
         ext = extras if include_background else extras[:, :1].contiguous()
         C = q_pos.shape[1]
+        # finalize=False: the merge of its splits rides in the dense loss's post-pass launch (ops.loss_post below)
         ins = ops.rowkey_infonce(q_pos, (1, C, 0, 1), B, queue, ext, temp_global,
-                                 grad_scale=(1.0 / B) if need_grad else None, want_lneg=want_lneg, lneg_row_major=True)
+                                 grad_scale=(1.0 / B) if need_grad else None, want_lneg=want_lneg, lneg_row_major=True,
+                                 finalize=False)
         # NegativeType (reference builder.py:1332-1386): the negative pairs' logits are squashed around 0 (FIXED) or
         # around the sample's mean / median negative score, which needs one un-reshaped pass first; HARD edits a copy
         # in the reference, i.e. it is the identity.
@@ -80,7 +82,8 @@ class _CP2LossFn(torch.autograd.Function):
                 centre = ops.masked_quantiles(pre.logits, P * P, 1, B, P * P, mask_a=mask_a, mask_b=mask_b, want=0)[1].contiguous()
             neg = (nscale, centre)
         den = ops.dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temp_local, ids, weights, want_logits=want_quart,
-                                    negative=neg)
+                                    negative=neg, defer_post=ins.pending is not None)
+        ops.loss_post(ins, den)
         if need_grad:
             # the dense kernel's split gradients stay un-summed: feat_bwd_fused adds them, and computes the pooled-vector
             # backward per workgroup (round 2: dense_grad_sum + pool_bwd + two fill kernels for dE)

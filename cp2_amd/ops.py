@@ -615,7 +615,7 @@ def tail_iou_supported(H: int, W: int, stride: int) -> bool:
 
 # ---------------------------------------------------------------- a10 / a16
 class RowKeyResult:
-    __slots__ = ("loss", "lse", "loss_rows", "cnt_gt", "drows", "dE", "lnegT", "lneg", "ksplit")
+    __slots__ = ("loss", "lse", "loss_rows", "cnt_gt", "drows", "dE", "lnegT", "lneg", "ksplit", "pending")
 
 
 def rowkey_infonce(rows: torch.Tensor, row_layout: Tuple[int, int, int, int], R: int, keys: torch.Tensor,
@@ -623,7 +623,7 @@ def rowkey_infonce(rows: torch.Tensor, row_layout: Tuple[int, int, int, int], R:
                    drows_like: Optional[torch.Tensor] = None, want_lneg: bool = False,
                    precision: str = "auto", presplit: bool = True, lneg_row_major: bool = False,
                    ksplit: Optional[torch.Tensor] = None, ksplit_ready: bool = False, lneg_out: Optional[torch.Tensor] = None,
-                   drows_out: Optional[torch.Tensor] = None) -> RowKeyResult:
+                   drows_out: Optional[torch.Tensor] = None, finalize: bool = True) -> RowKeyResult:
     """InfoNCE of R row vectors against the queue `keys` [C,K] with `extras` [R,NE] prepended
     (column 0 = positive).  row_layout = (RP, stride_n, stride_x, stride_c): element (c, r) of
     `rows` lives at (r//RP)*stride_n + (r%RP)*stride_x + c*stride_c.
@@ -692,12 +692,19 @@ def rowkey_infonce(rows: torch.Tensor, row_layout: Tuple[int, int, int, int], R:
     if want_grad:
         out.drows = drows_out if drows_out is not None else torch.empty_like(rows if drows_like is None else drows_like)
         out.dE = torch.empty((R, NE), dtype=torch.float32, device=dev)
-    rc = lib.cp2_rowkey_infonce_finalize(part_m.data_ptr(), part_s.data_ptr(), part_cnt.data_ptr(), _opt(part_U, "part_U"),
-                                         ns, extras.data_ptr(), NE, float(temperature),
-                                         float(grad_scale if want_grad else 0.0), R, RP, sn, sx, sc, out.lse.data_ptr(),
-                                         out.loss_rows.data_ptr(), out.cnt_gt.data_ptr(),
-                                         None if out.drows is None else out.drows.data_ptr(),
-                                         _opt(out.dE, "dE"), out.loss.data_ptr(), C, _stream())
+    fin = (part_m.data_ptr(), part_s.data_ptr(), part_cnt.data_ptr(), _opt(part_U, "part_U"),
+           ns, extras.data_ptr(), NE, float(temperature),
+           float(grad_scale if want_grad else 0.0), R, RP, sn, sx, sc, out.lse.data_ptr(),
+           out.loss_rows.data_ptr(), out.cnt_gt.data_ptr(),
+           None if out.drows is None else out.drows.data_ptr(),
+           _opt(out.dE, "dE"), out.loss.data_ptr())
+    out.pending = None
+    if not finalize and R <= 32 and ns >= 16:
+        # finalize=False: the merge of the splits is left to loss_post (one launch with the dense loss's post-pass); the
+        # partial buffers stay alive in `pending` until then.  Other shapes have no merged form: finalized here as usual.
+        out.pending = (fin, C, (part_m, part_s, part_cnt, part_U, extras))
+        return out
+    rc = lib.cp2_rowkey_infonce_finalize(*fin, C, _stream())
     _lib.check(rc, "cp2_rowkey_infonce_finalize")
     return out
 
@@ -773,7 +780,7 @@ def densecl_match(q_embed: torch.Tensor, k_embed: torch.Tensor, q_local: torch.T
 
 # ---------------------------------------------------------------- a8 / a9
 class DenseResult:
-    __slots__ = ("lse", "sample_scal", "colmax", "argx", "logits")
+    __slots__ = ("lse", "sample_scal", "colmax", "argx", "logits", "pending")
 
     @property
     def loss(self):          # mean_n loss_n (builder.py:1431-1437)
@@ -802,10 +809,11 @@ def _negative(negative):
 
 
 def dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temperature: float, ids=None,
-                      weights=(1.0, 1.0, 1.0), want_logits: bool = False, split: bool = True, negative=None) -> DenseResult:
+                      weights=(1.0, 1.0, 1.0), want_logits: bool = False, split: bool = True, negative=None,
+                      defer_post: bool = False) -> DenseResult:
     """Per-sample results in sample_scal [B,8] (Sa, Sb, loss_n, mean +score, mean -score, arg-max label): the batch means
     are formed by cp2_step_scalars in the step (`loss` / `acc` below are those means taken with tensor ops, for callers
-    outside the step)."""
+    outside the step).  defer_post: the fold of the splits and sample_scal are left to loss_post."""
     lib = _lib.load()
     nmode, nscale, ncen = _negative(negative)
     B, C, P = q_dense.shape
@@ -825,10 +833,34 @@ def dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temperature: float, ids=
                                    pa, pb, ra, rb, float(weights[0]), float(weights[1]), float(weights[2]),
                                    float(temperature), res.lse.data_ptr(), colsum.data_ptr(), possum.data_ptr(),
                                    allsum.data_ptr(), res.colmax.data_ptr(), res.argx.data_ptr(),
-                                   res.sample_scal.data_ptr(), _opt(res.logits, "logits"),
+                                   None if defer_post else res.sample_scal.data_ptr(), _opt(res.logits, "logits"),
                                    split_ws.data_ptr() if split_ws is not None else None, nmode, nscale, ncen, B, C, P, _stream())
     _lib.check(rc, "cp2_dense_infonce_fwd")
+    res.pending = None
+    if defer_post:
+        res.pending = ((_dev(mask_a, "mask_a", torch.float32), _dev(mask_b, "mask_b", torch.float32), res.lse.data_ptr(),
+                        colsum.data_ptr(), possum.data_ptr(), allsum.data_ptr(), res.colmax.data_ptr(), res.argx.data_ptr(),
+                        res.sample_scal.data_ptr(), split_ws.data_ptr() if split_ws is not None else None, B, C, P),
+                       (colsum, possum, allsum, split_ws, mask_a, mask_b))
     return res
+
+
+def loss_post(ins: RowKeyResult, den: DenseResult) -> None:
+    """Finish a rowkey_infonce(..., finalize=False) and a dense_infonce_fwd(..., defer_post=True) call with ONE launch
+    (cp2_loss_post); either argument whose work is not pending is left alone, a single pending one gets its own launch."""
+    lib = _lib.load()
+    if ins.pending is not None and den.pending is not None:
+        fin = ins.pending[0]
+        post = den.pending[0]
+        _profile("loss_post")
+        rc = lib.cp2_loss_post(*fin, *post, _stream())
+        _lib.check(rc, "cp2_loss_post")
+    elif ins.pending is not None:
+        rc = lib.cp2_rowkey_infonce_finalize(*ins.pending[0], ins.pending[1], _stream())
+        _lib.check(rc, "cp2_rowkey_infonce_finalize")
+    elif den.pending is not None:
+        raise _lib.Cp2LibraryError("loss_post: a deferred dense post-pass needs the instance loss's pending finalize beside it")
+    ins.pending = den.pending = None
 
 
 def dense_infonce_bwd(q_dense, k_dense, mask_a, mask_b, temperature: float, fwd: DenseResult, grad_scale: float,

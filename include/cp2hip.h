@@ -226,7 +226,9 @@ int cp2_rowkey_infonce_finalize(const float* part_m, const float* part_s, const 
  * negative_mode != 0 (reference NegativeType FIXED / AVERAGE / MEDIAN, builder.py:1332-1386): the raw logit L of every
  * NEGATIVE pair (mask_a[x]*mask_b[y] == 0) enters the loss as 2 / (1 + exp(-negative_scale * (L - centre))) - 1 with
  * centre = negative_center[n] (device float[B]: the sample's mean or median negative score, taken from a first
- * un-reshaped pass) or 0 when negative_center is NULL (FIXED); the logging sums always use the raw scores. */
+ * un-reshaped pass) or 0 when negative_center is NULL (FIXED); the logging sums always use the raw scores.
+ * sample_scal NULL: the fold of the splits and the per-sample scalars are DEFERRED -- the caller finishes the call with
+ * cp2_loss_post (same output arrays, same split_ws), which does that work beside the instance loss's finalize. */
 int cp2_dense_num_splits(int B, int P);
 int cp2_dense_infonce_fwd(const float* q_dense, const float* k_dense, const float* mask_a, const float* mask_b,
                           const int64_t* pix_a, const int64_t* pix_b, const int64_t* reg_a, const int64_t* reg_b,
@@ -235,6 +237,18 @@ int cp2_dense_infonce_fwd(const float* q_dense, const float* k_dense, const floa
                           float* sample_scal, float* logits_out, float* split_ws,
                           int negative_mode, float negative_scale, const float* negative_center, int B, int C,
                           int P, void* stream);
+/* One launch for two independent tails of the loss section (round 4): cp2_rowkey_infonce_finalize of the INSTANCE loss
+ * (its small-row form only: R <= 32, nsplit >= 16; arguments part_m .. loss_mean exactly as there) and the post-pass of a
+ * cp2_dense_infonce_fwd call that was given sample_scal = NULL (d_lse .. argx: that call's per-key-pixel arrays, split_ws:
+ * that call's workspace or NULL, mask_a / mask_b, sample_scal [B,8] as documented there).  Results equal the two separate
+ * launches' (bit for bit up to P = 256; beyond, the per-sample sums of the dense part are taken by 1024 instead of 256
+ * threads, i.e. in another fixed order). */
+int cp2_loss_post(const float* part_m, const float* part_s, const int32_t* part_cnt, const float* part_U, int nsplit,
+                  const float* extras, int NE, float temperature, float grad_scale, int R, int RP, int64_t d_sn,
+                  int64_t d_sx, int64_t d_sc, float* lse, float* loss_rows, int32_t* cnt_gt, float* drows, float* dE,
+                  float* loss_mean, const float* mask_a, const float* mask_b, float* d_lse, float* colsum_a,
+                  float* possum, float* allsum, float* colmax, int32_t* argx, float* sample_scal, float* split_ws,
+                  int B, int C, int P, void* stream);
 /* g_dense [B,C,P] = grad_scale * d (sum_n loss_n) / d q_dense, recomputing the logits tile by tile.
  * split_ws: NULL (g_dense receives the gradient), or float[S * B * C * P] with S = cp2_dense_num_splits(B, P): the
  * key-pixel range is shared by S workgroups; with S > 1 g_dense must be NULL and the S partial gradients [S][B][C][P]

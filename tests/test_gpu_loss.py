@@ -442,6 +442,50 @@ def test_rowkey_bf16x3_vs_oracle(R_rows, K):
     assert torch.equal(got.cnt_gt, exact.cnt_gt) or (got.cnt_gt - exact.cnt_gt).abs().max() <= 2
 
 
+@pytest.mark.parametrize("B,P,K,with_ids", [(32, 196, 65536, False), (5, 37, 4096, True), (8, 1024, 8192, False)])
+def test_loss_post_equals_the_two_separate_tail_launches(B, P, K, with_ids):
+    """cp2_loss_post = cp2_rowkey_infonce_finalize (instance loss) + the dense loss's post-pass in ONE launch (round 4).
+    Everything the two calls return is compared with the separately finalized calls: the instance side bit for bit; the
+    dense side bit for bit up to P = 256 (one key pixel per thread either way), beyond that the per-sample sums are taken by
+    1024 instead of 256 threads (another fixed order): 1e-6 relative."""
+    gen = torch.Generator().manual_seed(B * P)
+    C = 128
+    unit = lambda *shape, dim: torch.nn.functional.normalize(torch.randn(*shape, generator=gen), dim=dim).to(DEV)  # noqa: E731
+    qd, kd = unit(B, C, P, dim=1), unit(B, C, P, dim=1)
+    ma = (torch.rand(B, P, generator=gen) > 0.4).float().to(DEV)
+    mb = (torch.rand(B, P, generator=gen) > 0.5).float().to(DEV)
+    ids = None
+    if with_ids:
+        ids = tuple(torch.randint(0, 50, (B, P), generator=gen).to(DEV) for _ in range(4))
+    rows, queue = unit(B, C, dim=1), unit(C, K, dim=0)
+    ext = (torch.rand(B, 3, generator=gen) * 2 - 1).to(DEV)
+
+    def run(merged):
+        ins = ops.rowkey_infonce(rows, (1, C, 0, 1), B, queue, ext, 0.2, grad_scale=1.0 / B, want_lneg=True, lneg_row_major=True,
+                                 finalize=not merged)
+        den = ops.dense_infonce_fwd(qd, kd, ma, mb, 0.7, ids, (1.0, 0.7, 0.2), want_logits=True,
+                                    defer_post=merged and ins.pending is not None)
+        if merged:
+            assert ins.pending is not None and den.pending is not None
+            ops.loss_post(ins, den)
+            assert ins.pending is None and den.pending is None
+        return ins, den
+    (i0, d0), (i1, d1) = run(False), run(True)
+    for name in ("loss", "lse", "loss_rows", "cnt_gt", "drows", "dE", "lneg"):
+        assert torch.equal(getattr(i0, name), getattr(i1, name)), name
+    for name in ("lse", "colmax", "argx", "logits"):
+        assert torch.equal(getattr(d0, name), getattr(d1, name)), name
+    if P <= 256:
+        assert torch.equal(d0.sample_scal, d1.sample_scal)
+    else:
+        assert torch.equal(d0.sample_scal[:, [0, 1, 5]], d1.sample_scal[:, [0, 1, 5]])       # mask sums and the arg-max label: exact
+        for j in (2, 3, 4):                                                                     # loss_n, mean positive / negative score
+            assert_close(d1.sample_scal[:, j], d0.sample_scal[:, j], 1e-9, 2e-6, f"sample_scal[:, {j}]")
+    g0 = ops.dense_infonce_bwd(qd, kd, ma, mb, 0.7, d0, 0.1, ids, (1.0, 0.7, 0.2))
+    g1 = ops.dense_infonce_bwd(qd, kd, ma, mb, 0.7, d1, 0.1, ids, (1.0, 0.7, 0.2))
+    assert torch.equal(g0, g1)                                                                  # reads lse, Sa, Sb only
+
+
 @pytest.mark.parametrize("R_rows,K,grad,shift", [(640, 8192, True, 0), (200, 1008, True, 0), (75, 2064, False, 0), (333, 1040, False, 1)])
 def test_rowkey_bf16x3_row_major_logits_equal_the_key_major_ones(R_rows, K, grad, shift):
     """The row-major logits of the split-bf16 kernel (what the DenseCL score statistics read, builder.py:875-886) leave the
