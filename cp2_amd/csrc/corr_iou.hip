@@ -77,7 +77,7 @@ __global__ __launch_bounds__(1024) void corr_iou_kernel(const int64_t* __restric
     }
 }
 
-// Maps of up to 8191 cells per side (every training shape, config 4's 4096 included) are counted in an LDS hash table instead: tail.hip.
+// Maps of up to 4096 cells (every training shape, config 4's included) are counted in an LDS hash table instead: tail.hip.
 int cp2_tail_iou_table(int P);
 int cp2_tail_iou_launch(const int64_t* ids_a, const int64_t* ids_b, const float* mask_a, const float* mask_b, float* iou,
                         float* iou_masked, int B, int P, int H, int W, int stride, int Ws, void* stream);

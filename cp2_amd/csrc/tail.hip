@@ -159,7 +159,7 @@ __device__ __forceinline__ void enqueue_body(const EnqueueArgs& a, int b) {
 }
 
 // ---- part 2: a3-a5, IoU of two id maps by counting keys in an LDS hash table -- tools/correlation_mapping.py:103-138
-// The same counts without a sort, for maps of up to 8191 cells per side (the training shapes: P = 196 ... 4096): the
+// The same counts without a sort, for maps of up to 4096 cells (the training shapes: P = 196 ... 4096): the
 // 2P+1 keys go into an open-addressing table in LDS, load factor <= 1/2.  A slot is the key's bit pattern; "hit at least
 // twice" is one bit per slot in a bitmap behind the table: 4 bytes + 1 bit per slot, 66 KB for config 4's 4096-cell maps
 // (round 4; with a 4-byte count per slot the table stopped at 2047 cells and config 4 fell back to the 204 us
@@ -277,12 +277,12 @@ static int tail_fill_enqueue(TailArgs& t, float* queue, const float* keys, int64
     return CP2_OK;
 }
 
-// hash-count form only (maps of at most 8191 cells: table of 2 * N2 four-byte slots + its bitmap, <= 132 KB beside the
-// kernel's static 37 KB... so N2 <= 16384: 66 KB); *lds = the dynamic LDS it needs
+// hash-count form only: T = the power of two from 2 (2P + 1) - 2 up (load factor <= 1/2 + 1 slot: P = 4096 gives 16384 slots,
+// 66 KB with the bitmap, beside the kernel's 37 KB of static LDS), 0 = unsupported (more than 4096 cells per map)
 int cp2_tail_iou_table(int P) {
-    int N2 = 64;
-    while (N2 < 2 * P + 1) N2 <<= 1;
-    return N2 <= 16384 ? 2 * N2 : 0;
+    int T = 128;
+    while (T < 2 * (2 * P + 1) - 2) T <<= 1;
+    return T <= 16384 ? T : 0;
 }
 
 static int tail_fill_iou(TailArgs& t, size_t* lds, const int64_t* ids_a, const int64_t* ids_b, const float* mask_a, const float* mask_b,

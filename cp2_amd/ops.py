@@ -609,8 +609,8 @@ def step_tail(ins_loss, cnt_gt, extras, sample_scal, q_pos, k_pos, lmbd_dense: f
 
 
 def tail_iou_supported(H: int, W: int, stride: int) -> bool:
-    """The IoU part of step_tail counts keys in an LDS hash table: at most 8191 down-sampled cells per map."""
-    return 2 * ds_size(H, stride) * ds_size(W, stride) + 1 <= 16384
+    """The IoU part of step_tail counts keys in an LDS hash table: at most 4096 down-sampled cells per map."""
+    return ds_size(H, stride) * ds_size(W, stride) <= 4096
 
 
 # ---------------------------------------------------------------- a10 / a16

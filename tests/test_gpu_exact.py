@@ -138,10 +138,10 @@ def test_corr_iou_kats(golden_dir, tag):
         assert torch.equal(iou.cpu(), torch.tensor([4 / 7])) and torch.equal(ioum.cpu(), torch.tensor([2 / 3]))
 
 
-# P <= 8191: keys counted in an LDS hash table (round 3: up to 2047); above: bitonic sort (both forms, the boundary between
+# P <= 4096: keys counted in an LDS hash table (round 3: up to 2047); above: bitonic sort (both forms, the boundary between
 # them, and the old boundary); the last case has ids below -1 (keys of either sign)
 @pytest.mark.parametrize("B,P,hi,lo", [(32, 196, 60000, 0), (8, 4096, 5000, 0), (5, 1, 3, 0), (4, 1024, 1 << 30, 0), (2, 16383, 100, 0),
-                                       (3, 2047, 900, 0), (3, 2048, 900, 0), (6, 196, 4, 0), (3, 8191, 3000, 0), (3, 8192, 3000, 0),
+                                       (3, 2047, 900, 0), (3, 2048, 900, 0), (6, 196, 4, 0), (3, 4097, 3000, 0), (3, 8192, 3000, 0),
                                        (8, 4096, 1 << 40, 0), (4, 300, 40, -40)])
 def test_corr_iou_random_vs_oracle(B, P, hi, lo):
     gen = torch.Generator().manual_seed(P)
