@@ -53,6 +53,9 @@ SIGNATURES = {
                               _P, _P, _P, _P, _P, c_int, c_float, _P, c_int, c_int, c_int, _P],
     "cp2_loss_post": [_P, _P, _P, _P, c_int, _P, c_int, c_float, c_float, c_int, c_int, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P,
                       _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
+    "cp2_step_post": [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P,
+                      _P, _P, _P, _P, c_int, _P, c_int, c_float, c_float, c_int, c_int, c_int64, c_int64, c_int64, _P, _P, _P, _P, _P,
+                      _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
     "cp2_crop_resize_flip": [_P, c_int, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P],
     "cp2_pil_resize_ksize": [c_int, c_int, c_int, c_int],
     "cp2_pil_resize_workspace_bytes": [c_int, c_int, c_int, c_int, c_int],

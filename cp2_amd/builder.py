@@ -88,7 +88,8 @@ class DenseCLNeck(nn.Module):
         # encoder.Conv2d = nn.Conv2d (same parameter names) that reads the bf16 weight image under bf16 autocast and sends wide
         # 1x1 layers through the GEMM / cp2_wgrad1x1 nodes, like the backbone's layers
         from .encoder import Conv2d
-        cnv = lambda a, b, c: nn.Sequential(Conv2d(a, b, 1), nn.ReLU(inplace=True), Conv2d(b, c, 1))  # noqa: E731
+        # (ReLU out of place: the GEMM-routed 1x1 node returns a view of its matrix product, which autograd refuses to modify)
+        cnv = lambda a, b, c: nn.Sequential(Conv2d(a, b, 1), nn.ReLU(inplace=False), Conv2d(b, c, 1))  # noqa: E731
         self.global_projector = mlp(in_channels, hid_channels, out_channels)
         self.global_predictor = mlp(out_channels, hid_channels, out_channels)
         self.with_pool = num_grid is not None

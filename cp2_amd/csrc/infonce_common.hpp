@@ -30,6 +30,28 @@ struct RowKeyFinArgs {
     float* lse; float* loss_rows; int* cnt_gt; float* drows; float* dE;
 };
 
+// dense (pixel-to-pixel) InfoNCE of one sample pair: infonce.hip
+struct DenseArgs {
+    const float* qd; const float* kd;            // [B][CH][P] unit vectors per pixel
+    const float* mask_a; const float* mask_b;    // [B][P]
+    const int64_t* pix_a; const int64_t* pix_b;  // [B][P] or NULL (all weights 1)
+    const int64_t* reg_a; const int64_t* reg_b;
+    float w_pixel, w_region, w_not, inv_t;
+    int P;
+    // forward outputs, per key pixel y: [B][P]
+    float* lse; float* colsum_a; float* possum; float* allsum; float* colmax; int* argx;
+    float* logits_out;                           // optional [B][P][P] raw logits (x-major), for the logging quantiles
+    // backward
+    const float* sample_scal;                    // [B][8]: Sa, Sb, ...
+    float grad_scale; float* g_dense;            // [B][CH][P]
+    // forward, split over the query pixels x: S > 1 workgroups share a (sample, key tile) and write partial column
+    // statistics part[7][S][B*P] = (max, sum exp, colsum_a, possum, allsum, best value, best x); dense_post_body
+    // folds them into the per-key outputs above
+    int splits; float* part;
+    // NegativeType reshaping of the negative pairs' raw logits (builder.py:1332-1386): L -> 2 / (1 + exp(-scale (L - centre))) - 1
+    float neg_scale; const float* neg_center;    // centre per sample [B], or NULL = 0 (FIXED)
+};
+
 // Small-R form (R <= 32 rows, K % 4 == 0, 16-byte aligned keys): rowkey_small.hip
 int rowkey_small_num_splits(int K, int* tiles_per_wg);
 int rowkey_small_launch(const RowKeyArgs& a, int nsplit, bool with_u, hipStream_t stream);

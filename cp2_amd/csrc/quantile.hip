@@ -30,6 +30,8 @@
 // the P x P logits in every pass costs three more MFMA passes (3 x 0.44 ms at config 4) against 0.36 ms for writing
 // them once and reading them three times at HBM speed.
 #include "common.hpp"
+#include "rowkey_small_fin.hpp"
+#include "dense_post.hpp"
 #include <math.h>
 
 struct QuantArgs {
@@ -969,10 +971,11 @@ __device__ __forceinline__ void qrow_body_cached(const QuantArgs& a, int r, cons
     }
 }
 
-__global__ __launch_bounds__(QT3) void quantiles_row_kernel(QuantJobs jobs) {
+// `block` = the row, counted over all jobs (the kernels below pass blockIdx.x or blockIdx.x minus their rider workgroups)
+__device__ __forceinline__ void quantiles_row_block(const QuantJobs& jobs, int block) {
     int jsel = 0;
 #pragma unroll
-    for (int j = 1; j < QJOBS; ++j) jsel += ((int)blockIdx.x >= jobs.first_row[j]) ? 1 : 0;
+    for (int j = 1; j < QJOBS; ++j) jsel += (block >= jobs.first_row[j]) ? 1 : 0;
     const QuantArgs& a = jobs.job[jsel];
     extern __shared__ __attribute__((aligned(16))) unsigned char q_smem[];
     __shared__ unsigned hist0[QB0];
@@ -986,7 +989,7 @@ __global__ __launch_bounds__(QT3) void quantiles_row_kernel(QuantJobs jobs) {
     S.sum_w = sum_w;
     S.lma = reinterpret_cast<float*>(q_smem);
     S.lmb = S.lma + (masked ? a.P : 0);
-    const int r = (int)blockIdx.x - jobs.first_row[jsel], tid = threadIdx.x;
+    const int r = block - jobs.first_row[jsel], tid = threadIdx.x;
     if (masked) {
         for (int i = tid; i < a.P; i += QT3) { S.lma[i] = a.mask_a[(int64_t)r * a.P + i]; S.lmb[i] = a.mask_b[(int64_t)r * a.P + i]; }
     }
@@ -1004,6 +1007,20 @@ __global__ __launch_bounds__(QT3) void quantiles_row_kernel(QuantJobs jobs) {
     } else {
         if (masked) qrow_body<true, QMAX>(a, r, S); else qrow_body<false, QMAX>(a, r, S);
     }
+}
+
+__global__ __launch_bounds__(QT3) void quantiles_row_kernel(QuantJobs jobs) { quantiles_row_block(jobs, (int)blockIdx.x); }
+
+// The step's form (round 4): the quartile rows AND the two tails of the loss section that depend on nothing the quartiles
+// write -- the instance loss's finalize (rowkey_small_finalize_body, nfin workgroups) and the dense loss's post-pass (one
+// workgroup per sample) -- in ONE launch.  The riders come first in the grid (they are short; the 96 row workgroups of the
+// bench step need 42 us); all of them have 1024 threads.  cp2_step_post, see include/cp2hip.h.
+__global__ __launch_bounds__(QT3) void step_post_kernel(QuantJobs jobs, RowKeyFinArgs fa, float* __restrict__ loss_mean, DenseArgs da,
+                                                        float* __restrict__ sample_scal, int64_t BP, int nfin, int npost) {
+    const int b = (int)blockIdx.x;
+    if (b < nfin) { rowkey_small_finalize_body(fa, loss_mean, b); return; }
+    if (b < nfin + npost) { dense_post_body<QT3>(da, sample_scal, BP, b - nfin); return; }
+    quantiles_row_block(jobs, b - nfin - npost);
 }
 
 static int quant_check(const QuantArgs& a) {
@@ -1028,9 +1045,15 @@ CP2_API int64_t cp2_quantiles_workspace_bytes(int njobs, const int* R, const int
     return 4 * quant_ws_words(njobs, R, N, NQ);
 }
 
-static int quant_launch(QuantJobs& jobs, int njobs, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+struct QuantRider {                                        // the loss-section tails that ride in the row launch (cp2_step_post)
+    RowKeyFinArgs fa; float* loss_mean; DenseArgs da; float* sample_scal; int B;
+};
+
+static int quant_launch(QuantJobs& jobs, int njobs, void* workspace, int64_t workspace_bytes, hipStream_t stream,
+                        const QuantRider* rider = nullptr) {
     bool small = true;
     for (int j = 0; j < njobs; ++j) small = small && jobs.job[j].N <= QROW_MAX;
+    if (rider && !small) return CP2_ERR_UNSUPPORTED;       // long rows: cp2_loss_post + cp2_masked_quantiles_multi
     if (small) {                                           // one launch, one workgroup per row, no workspace
         size_t lds = 0;
         int rows = 0;
@@ -1043,6 +1066,12 @@ static int quant_launch(QuantJobs& jobs, int njobs, void* workspace, int64_t wor
             rows += jobs.job[j].R;
         }
         for (int j = njobs; j <= QJOBS; ++j) jobs.first_row[j] = rows;
+        if (rider) {
+            const int nfin = CH / FS2_CPB;
+            CP2_LAUNCH_PROFILED(step_post_kernel, dim3(nfin + rider->B + rows), dim3(QT3), lds, stream, jobs, rider->fa, rider->loss_mean,
+                                rider->da, rider->sample_scal, (int64_t)rider->B * rider->da.P, nfin, rider->B);
+            return cp2_launch_status();
+        }
         CP2_LAUNCH_PROFILED(quantiles_row_kernel, dim3(rows), dim3(QT3), lds, stream, jobs);
         return cp2_launch_status();
     }
@@ -1115,4 +1144,29 @@ CP2_API int cp2_masked_quantiles_multi(int njobs, const float* const* x, const i
         jobs.job[j] = QuantArgs{x[j], stride_row[j], stride_elem[j], N[j], mask_a[j], mask_b[j], P[j], want[j], q, NQ, out[j], R[j], 0,
                                 mean_out ? mean_out[j] : nullptr, 0};
     return quant_launch(jobs, njobs, workspace, workspace_bytes, cp2_stream(stream));
+}
+
+// cp2_masked_quantiles_multi (its one-launch row form only: every N <= CP2_QUANTILES_ROW_MAX) + cp2_loss_post in ONE launch
+CP2_API int cp2_step_post(int njobs, const float* const* x, const int64_t* stride_row, const int64_t* stride_elem,
+                          const int* R, const int* N, const float* const* mask_a, const float* const* mask_b,
+                          const int* P, const int* want, const float* q, int NQ, float* const* out, float* const* mean_out,
+                          const float* part_m, const float* part_s, const int32_t* part_cnt, const float* part_U, int nsplit,
+                          const float* extras, int NE, float temperature, float grad_scale, int fR, int RP, int64_t d_sn,
+                          int64_t d_sx, int64_t d_sc, float* lse, float* loss_rows, int32_t* cnt_gt, float* drows, float* dE,
+                          float* loss_mean, const float* d_mask_a, const float* d_mask_b, float* d_lse, float* colsum_a,
+                          float* possum, float* allsum, float* colmax, int32_t* argx, float* sample_scal, float* split_ws,
+                          int B, int C, int dP, void* stream) {
+    if (njobs <= 0 || njobs > QJOBS) return CP2_ERR_UNSUPPORTED;
+    if (!x || !stride_row || !stride_elem || !R || !N || !mask_a || !mask_b || !P || !want || !out) return CP2_ERR_NULL;
+    QuantRider rider{};
+    int rc = loss_post_fill(part_m, part_s, part_cnt, part_U, nsplit, extras, NE, temperature, grad_scale, fR, RP, d_sn, d_sx, d_sc, lse,
+                            loss_rows, cnt_gt, drows, dE, d_mask_a, d_mask_b, d_lse, colsum_a, possum, allsum, colmax, argx, sample_scal,
+                            split_ws, B, C, dP, &rider.fa, &rider.da);
+    if (rc) return rc;
+    rider.loss_mean = loss_mean; rider.sample_scal = sample_scal; rider.B = B;
+    QuantJobs jobs{};
+    for (int j = 0; j < njobs; ++j)
+        jobs.job[j] = QuantArgs{x[j], stride_row[j], stride_elem[j], N[j], mask_a[j], mask_b[j], P[j], want[j], q, NQ, out[j], R[j], 0,
+                                mean_out ? mean_out[j] : nullptr, 0};
+    return quant_launch(jobs, njobs, nullptr, 0, cp2_stream(stream), &rider);
 }

@@ -83,7 +83,20 @@ class _CP2LossFn(torch.autograd.Function):
             neg = (nscale, centre)
         den = ops.dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temp_local, ids, weights, want_logits=want_quart,
                                     negative=neg, defer_post=ins.pending is not None)
-        ops.loss_post(ins, den)
+        # the two tails (and, with quartile logging, the step's three quartile sets) in one launch: cp2_step_post / cp2_loss_post
+        qs = (None, None, None)
+        lneg_mean = None
+        jobs = None
+        if want_quart:
+            K = queue.shape[1]
+            dense = dict(x=den.logits, stride_row=P * P, stride_elem=1, R=B, N=P * P, mask_a=mask_a, mask_b=mask_b)
+            row_form = K <= ops.QUANTILES_ROW_MAX and P * P <= ops.QUANTILES_ROW_MAX
+            lneg_mean = torch.empty(B, dtype=torch.float32, device=q_feat.device) if row_form else ins.lneg.mean(1)
+            jobs = [dict(dense, want=1), dict(dense, want=0),
+                    dict(x=ins.lneg, stride_row=K, stride_elem=1, R=B, N=K, mean_out=lneg_mean if row_form else None)]
+        outs = ops.loss_post(ins, den, jobs)
+        if outs is not None:
+            qs = outs
         if need_grad:
             # the dense kernel's split gradients stay un-summed: feat_bwd_fused adds them, and computes the pooled-vector
             # backward per workgroup (round 2: dense_grad_sum + pool_bwd + two fill kernels for dE)
@@ -92,16 +105,6 @@ class _CP2LossFn(torch.autograd.Function):
             dq = ops.feat_bwd_fused(q_dense, q_inv, mask_a, g_part, S, ins.drows, ins.dE, q_pos, q_neg, k_pos, k_neg, q_norms,
                                     include_background, q_feat)
             ctx.save_for_backward(dq)
-        qs = (None, None, None)
-        lneg_mean = None
-        if want_quart:
-            K = queue.shape[1]
-            dense = dict(x=den.logits, stride_row=P * P, stride_elem=1, R=B, N=P * P, mask_a=mask_a, mask_b=mask_b)
-            row_form = K <= ops.QUANTILES_ROW_MAX and P * P <= ops.QUANTILES_ROW_MAX
-            lneg_mean = torch.empty(B, dtype=torch.float32, device=q_feat.device) if row_form else ins.lneg.mean(1)
-            qs = ops.masked_quantiles_multi([dict(dense, want=1), dict(dense, want=0),       # one launch for all three
-                                             dict(x=ins.lneg, stride_row=K, stride_elem=1, R=B, N=K,
-                                                  mean_out=lneg_mean if row_form else None)])
         # every scalar the step returns or logs: one launch (the loss combination included) -- and, when the caller hands over
         # the step's tail (`tail`), the keys' enqueue and the logged IoUs ride in the same launch (cp2_step_tail)
         iou = iou_masked = None

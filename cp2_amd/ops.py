@@ -845,10 +845,23 @@ def dense_infonce_fwd(q_dense, k_dense, mask_a, mask_b, temperature: float, ids=
     return res
 
 
-def loss_post(ins: RowKeyResult, den: DenseResult) -> None:
+def loss_post(ins: RowKeyResult, den: DenseResult, quant_jobs=None, q: Optional[torch.Tensor] = None):
     """Finish a rowkey_infonce(..., finalize=False) and a dense_infonce_fwd(..., defer_post=True) call with ONE launch
-    (cp2_loss_post); either argument whose work is not pending is left alone, a single pending one gets its own launch."""
+    (cp2_loss_post); either argument whose work is not pending is left alone, a single pending one gets its own launch.
+    quant_jobs (a masked_quantiles_multi job list): the step's quartile statistics too -- in the SAME launch when both tails
+    are pending and every row fits the one-launch quantile form (cp2_step_post), by masked_quantiles_multi otherwise;
+    returns their outputs (None without quant_jobs)."""
     lib = _lib.load()
+    if (quant_jobs is not None and ins.pending is not None and den.pending is not None
+            and all(j["N"] <= QUANTILES_ROW_MAX for j in quant_jobs)):
+        if q is None:
+            q = _quartile_tensor(quant_jobs[0]["x"].device)
+        args, outs = _quant_job_args(quant_jobs, q)
+        _profile("quantiles")
+        rc = lib.cp2_step_post(*args, *ins.pending[0], *den.pending[0], _stream())
+        _lib.check(rc, "cp2_step_post")
+        ins.pending = den.pending = None
+        return outs
     if ins.pending is not None and den.pending is not None:
         fin = ins.pending[0]
         post = den.pending[0]
@@ -861,6 +874,7 @@ def loss_post(ins: RowKeyResult, den: DenseResult) -> None:
     elif den.pending is not None:
         raise _lib.Cp2LibraryError("loss_post: a deferred dense post-pass needs the instance loss's pending finalize beside it")
     ins.pending = den.pending = None
+    return masked_quantiles_multi(quant_jobs, q) if quant_jobs is not None else None
 
 
 def dense_infonce_bwd(q_dense, k_dense, mask_a, mask_b, temperature: float, fwd: DenseResult, grad_scale: float,
@@ -940,12 +954,29 @@ def masked_quantiles(x: torch.Tensor, stride_row: int, stride_elem: int, R: int,
 def masked_quantiles_multi(jobs, q: Optional[torch.Tensor] = None):
     """Several masked_quantiles problems in one call.  jobs: list of dicts with the keyword arguments of
     masked_quantiles (x, stride_row, stride_elem, R, N, mask_a, mask_b, want); returns the list of outputs."""
-    import ctypes
     lib = _lib.load()
-    n = len(jobs)
     dev = jobs[0]["x"].device
     if q is None:
         q = _quartile_tensor(dev)
+    args, outs = _quant_job_args(jobs, q)
+    # rows of at most QUANTILES_ROW_MAX elements: one launch, one workgroup per row, no workspace; longer rows: the chunked
+    # six-launch path with its zeroed workspace
+    small = all(j["N"] <= QUANTILES_ROW_MAX for j in jobs)
+    ws = None if small else _quant_workspace(dev, [j["R"] for j in jobs], [j["N"] for j in jobs], q.numel())
+    _profile("quantiles")
+    rc = lib.cp2_masked_quantiles_multi(*args, None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel() * 4, _stream())
+    if rc and ws is not None:
+        ws.zero_()                                        # a failed call may have left counts behind
+    _lib.check(rc, "cp2_masked_quantiles_multi")
+    return outs
+
+
+def _quant_job_args(jobs, q: torch.Tensor):
+    """The leading arguments (njobs .. mean_out) of cp2_masked_quantiles_multi / cp2_step_post for a job list, and the output
+    tensors they point at."""
+    import ctypes
+    n = len(jobs)
+    dev = jobs[0]["x"].device
     outs = [torch.empty((q.numel(), j["R"]), dtype=torch.float32, device=dev) for j in jobs]
     # job key "mean_out": a float32 [R] tensor that receives the row means (one-launch form, unmasked jobs only)
     means = [_opt(j.get("mean_out"), "mean_out", torch.float32) for j in jobs]
@@ -956,22 +987,12 @@ def masked_quantiles_multi(jobs, q: Optional[torch.Tensor] = None):
             raise _lib.Cp2LibraryError("masked_quantiles: x must be a float32 GPU tensor")
     ma = [_opt(j.get("mask_a"), "mask_a", torch.float32) for j in jobs]
     mb = [_opt(j.get("mask_b"), "mask_b", torch.float32) for j in jobs]
-    # rows of at most QUANTILES_ROW_MAX elements: one launch, one workgroup per row, no workspace; longer rows: the chunked
-    # six-launch path with its zeroed workspace
-    small = all(j["N"] <= QUANTILES_ROW_MAX for j in jobs)
-    ws = None if small else _quant_workspace(dev, [j["R"] for j in jobs], [j["N"] for j in jobs], q.numel())
-    _profile("quantiles")
-    rc = lib.cp2_masked_quantiles_multi(
-        n, P_(*[j["x"].data_ptr() for j in jobs]), I64(*[j["stride_row"] for j in jobs]), I64(*[j["stride_elem"] for j in jobs]),
-        I32(*[j["R"] for j in jobs]), I32(*[j["N"] for j in jobs]), P_(*ma), P_(*mb),
-        I32(*[(j["mask_a"].shape[1] if j.get("mask_a") is not None else 0) for j in jobs]),
-        I32(*[j.get("want", -1) for j in jobs]), _dev(q, "q", torch.float32), q.numel(), P_(*[o.data_ptr() for o in outs]),
-        P_(*means) if any(m is not None for m in means) else None,
-        None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel() * 4, _stream())
-    if rc and ws is not None:
-        ws.zero_()                                        # a failed call may have left counts behind
-    _lib.check(rc, "cp2_masked_quantiles_multi")
-    return outs
+    args = (n, P_(*[j["x"].data_ptr() for j in jobs]), I64(*[j["stride_row"] for j in jobs]), I64(*[j["stride_elem"] for j in jobs]),
+            I32(*[j["R"] for j in jobs]), I32(*[j["N"] for j in jobs]), P_(*ma), P_(*mb),
+            I32(*[(j["mask_a"].shape[1] if j.get("mask_a") is not None else 0) for j in jobs]),
+            I32(*[j.get("want", -1) for j in jobs]), _dev(q, "q", torch.float32), q.numel(), P_(*[o.data_ptr() for o in outs]),
+            P_(*means) if any(m is not None for m in means) else None)
+    return args, outs
 
 
 # ---------------------------------------------------------------- encoder fast path: fused BatchNorm

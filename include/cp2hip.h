@@ -249,6 +249,21 @@ int cp2_loss_post(const float* part_m, const float* part_s, const int32_t* part_
                   float* loss_mean, const float* mask_a, const float* mask_b, float* d_lse, float* colsum_a,
                   float* possum, float* allsum, float* colmax, int32_t* argx, float* sample_scal, float* split_ws,
                   int B, int C, int P, void* stream);
+/* The same two tails riding in the launch of the step's quartile statistics (round 4: one launch instead of three):
+ * arguments njobs .. mean_out exactly as cp2_masked_quantiles_multi (its one-launch row form only: every N <=
+ * CP2_QUANTILES_ROW_MAX, else CP2_ERR_UNSUPPORTED -- use cp2_loss_post + cp2_masked_quantiles_multi), then part_m ..
+ * loss_mean and d_mask_a .. dP exactly as cp2_loss_post (fR = its R, dP = its P).  The quartile jobs may read the logits the
+ * two producer kernels wrote (lnegT of cp2_rowkey_infonce_fwd, logits_out of cp2_dense_infonce_fwd): none of the three
+ * parts reads what another writes.  Quartiles bit-equal to cp2_masked_quantiles_multi, the tails to cp2_loss_post. */
+int cp2_step_post(int njobs, const float* const* x, const int64_t* stride_row, const int64_t* stride_elem,
+                  const int* R, const int* N, const float* const* mask_a, const float* const* mask_b,
+                  const int* P, const int* want, const float* q, int NQ, float* const* out, float* const* mean_out,
+                  const float* part_m, const float* part_s, const int32_t* part_cnt, const float* part_U, int nsplit,
+                  const float* extras, int NE, float temperature, float grad_scale, int fR, int RP, int64_t d_sn,
+                  int64_t d_sx, int64_t d_sc, float* lse, float* loss_rows, int32_t* cnt_gt, float* drows, float* dE,
+                  float* loss_mean, const float* d_mask_a, const float* d_mask_b, float* d_lse, float* colsum_a,
+                  float* possum, float* allsum, float* colmax, int32_t* argx, float* sample_scal, float* split_ws,
+                  int B, int C, int dP, void* stream);
 /* g_dense [B,C,P] = grad_scale * d (sum_n loss_n) / d q_dense, recomputing the logits tile by tile.
  * split_ws: NULL (g_dense receives the gradient), or float[S * B * C * P] with S = cp2_dense_num_splits(B, P): the
  * key-pixel range is shared by S workgroups; with S > 1 g_dense must be NULL and the S partial gradients [S][B][C][P]

@@ -460,17 +460,32 @@ def test_loss_post_equals_the_two_separate_tail_launches(B, P, K, with_ids):
     rows, queue = unit(B, C, dim=1), unit(C, K, dim=0)
     ext = (torch.rand(B, 3, generator=gen) * 2 - 1).to(DEV)
 
-    def run(merged):
+    def jobs_of(ins, den, mean_out):
+        dense = dict(x=den.logits, stride_row=P * P, stride_elem=1, R=B, N=P * P, mask_a=ma, mask_b=mb)
+        return [dict(dense, want=1), dict(dense, want=0), dict(x=ins.lneg, stride_row=K, stride_elem=1, R=B, N=K, mean_out=mean_out)]
+
+    def run(merged, with_quartiles=False):
         ins = ops.rowkey_infonce(rows, (1, C, 0, 1), B, queue, ext, 0.2, grad_scale=1.0 / B, want_lneg=True, lneg_row_major=True,
                                  finalize=not merged)
         den = ops.dense_infonce_fwd(qd, kd, ma, mb, 0.7, ids, (1.0, 0.7, 0.2), want_logits=True,
                                     defer_post=merged and ins.pending is not None)
+        mean = torch.empty(B, device=DEV)
         if merged:
             assert ins.pending is not None and den.pending is not None
-            ops.loss_post(ins, den)
+            quart = ops.loss_post(ins, den, jobs_of(ins, den, mean) if with_quartiles else None)
             assert ins.pending is None and den.pending is None
-        return ins, den
-    (i0, d0), (i1, d1) = run(False), run(True)
+        else:
+            quart = ops.masked_quantiles_multi(jobs_of(ins, den, mean))
+        return ins, den, quart, mean
+    (i0, d0, q0, m0), (i1, d1, _, _) = run(False), run(True)
+    # ... and with the step's three quartile sets riding in the same launch (cp2_step_post; row form only: P * P <= 131072)
+    if P * P <= ops.QUANTILES_ROW_MAX:
+        i2, d2, q2, m2 = run(True, with_quartiles=True)
+        for a_, b_ in zip(q0, q2):
+            assert torch.equal(a_, b_) or (torch.equal(torch.isnan(a_), torch.isnan(b_)) and torch.equal(a_.nan_to_num(), b_.nan_to_num()))
+        assert torch.equal(m0, m2)
+        assert torch.equal(i0.loss_rows, i2.loss_rows) and torch.equal(i0.drows, i2.drows) and torch.equal(d1.sample_scal, d2.sample_scal)
+        assert torch.equal(i0.loss, i2.loss) and torch.equal(i0.cnt_gt, i2.cnt_gt) and torch.equal(i0.dE, i2.dE)
     for name in ("loss", "lse", "loss_rows", "cnt_gt", "drows", "dE", "lneg"):
         assert torch.equal(getattr(i0, name), getattr(i1, name)), name
     for name in ("lse", "colmax", "argx", "logits"):

@@ -109,13 +109,16 @@ def test_densecl_neck_under_autocast_stays_close_to_the_fp32_neck():
         model.neck_autocast = neck_amp
         model.encoder_q.to(memory_format=torch.channels_last)
         model.encoder_k.to(memory_format=torch.channels_last)
+        model.flatten_parameters()
+        model.enable_query_shadow()                     # what optim.FlatSGD does: the query convolutions read a bf16 weight image
         batch = synthetic.make_batch(4, 64, 64, DEV, seed=5)
         loss = model(visualize=False, step=0, new_epoch=False, idx_shuffle=torch.arange(4, device=DEV), **batch)
         loss.backward()
         neck = model.encoder_q.neck
         out[neck_amp] = (float(loss), [p.grad.clone() for p in list(neck.local_projector.parameters()) + list(neck.global_projector.parameters())])
         if neck_amp:
-            assert neck.local_projector[0].shadow_weight is not None and neck.local_projector[0].shadow_weight.dtype == torch.bfloat16
+            for nk in (neck, model.encoder_k.neck):
+                assert nk.local_projector[0].shadow_weight is not None and nk.local_projector[0].shadow_weight.dtype == torch.bfloat16
     assert abs(out[True][0] - out[False][0]) <= 0.02 * abs(out[False][0]), (out[True][0], out[False][0])
     for ga, gf in zip(out[True][1], out[False][1]):
         assert torch.isfinite(ga).all()
