@@ -511,7 +511,8 @@ def main():
         "builder.py:818-864)", "mfma", 2.0 * b * P * P * CE, "TFLOP/s", BF16_DENSE_PEAK_TFLOPS,
         "bf16 MFMA on the backbone features as the encoder returns them (exact products, fp32 accumulation); at P=196 the launch is "
         "bound by streaming the two 25.7 MB feature maps and by its 224 work items, not by the matrix pipe")
-    add("quantiles", "quantiles kernels (the logging quartiles of the step)", "hbm",
+    add("quantiles", "quantiles kernels (the logging quartiles of the step)" if args.densecl or K > 131072 or P * P > 131072 else
+        "step_post_kernel (the step's quartile rows; the instance-loss finalize and the dense post-pass ride in the same launch)", "hbm",
         4 * ((b * K + 2 * b * P * P) if not args.densecl else (b * P * K + b * K) / max(1.0, len(prof.get("quantiles") or [1]) / args.steps)),
         "GB/s", HBM_PEAK_GBS, "radix select over rows kept in registers: latency / LDS-atomic bound, not a streaming kernel")
     if sgd_entry is not None:

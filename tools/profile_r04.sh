@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r04; mkdir -p $O
 WHAT=${*:-cfg2 cfg5 cfg4 micro lines}
-LOSSK="rowkey quantile dense_ step_tail feat_ pool_ corr_iou compose strided gather_rows ema_ sgd_ densecl_match keys_split"
+LOSSK="rowkey quantile dense_ step_tail step_post loss_post feat_ pool_ corr_iou compose strided gather_rows ema_ sgd_ densecl_match keys_split"
 cd /tmp
 for W in cfg2 cfg5 cfg4; do
   case " $WHAT " in *" $W "*) ;; *) continue;; esac

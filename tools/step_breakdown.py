@@ -25,7 +25,7 @@ def cat(n):
     if 'maxpool3s2' in n: return 'stem max-pool (csrc/pool.hip)'
     if any(k in n for k in ('ema_flat', 'sgd_flat', 'bf16_image')): return 'EMA + optimizer kernels (csrc/ema.hip, sgd.hip)'
     if any(k in n for k in ('rowkey', 'dense_', 'quantile', 'feat_', 'pool_', 'compose', 'strided_gather', 'gather_rows',
-                            'corr_iou', 'enqueue', 'keys_split', 'mean_kernel', 'step_scalars', 'step_tail', 'densecl_match')): return 'loss-section kernels (csrc/*.hip)'
+                            'corr_iou', 'enqueue', 'keys_split', 'mean_kernel', 'step_scalars', 'step_tail', 'step_post', 'loss_post', 'densecl_match')): return 'loss-section kernels (csrc/*.hip)'
     if any(k in n for k in ('igemm', 'ck::', '_ZN2ck', 'SubTensorOp', 'Cijk', 'miopen', 'MIOpen', 'naive_conv', 'gemm')): return 'MIOpen / CK / hipBLASLt (convolutions, GEMMs)'
     if 'rocclr' in n: return 'runtime fills / copies'
     return 'ATen elementwise / pooling / reductions'
