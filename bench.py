@@ -426,7 +426,11 @@ def main():
         evs = prof.get(name) or []
         return sum(e.elapsed_ms() for e in evs) / len(evs) if evs else None
 
-    def hbm_entry(kernel, ms, alg_per_slot, fused_per_slot, traffic_file, what):
+    # the optimizer kernel skips the slots of frozen parameters (no gradient pointer: the decode head on the DenseCL path,
+    # conv_seg on the CP2 path); the EMA walks the whole flat buffer
+    sgd_slots = sum((p.numel() + 63) // 64 * 64 for p in model.encoder_q.parameters() if p.requires_grad)
+
+    def hbm_entry(kernel, ms, alg_per_slot, fused_per_slot, traffic_file, what, n_slots=n_slots):
         """achieved = ALGORITHMIC bytes / kernel time; the fused figure counts the bf16 weight image the same
         pass also writes (2 B per slot), i.e. what the launch really moves."""
         alg, fused = alg_per_slot * n_slots, fused_per_slot * n_slots
@@ -449,7 +453,9 @@ def main():
         qshadow = model._flat_q_bf16 is not None
         sgd_entry = hbm_entry("sgd_flat_kernel (SGD momentum + weight decay, main.py:467-477,640-642)", sgd_ms, 20,
                               22 if qshadow else 20, "sgd_traffic.json",
-                              "algorithmic: read p, g, momentum; write p, momentum in fp32; fused: + the bf16 image of the new query weights")
+                              "algorithmic: read p, g, momentum; write p, momentum in fp32; fused: + the bf16 image of the new query weights"
+                              + ("" if sgd_slots == n_slots else f"; {n_slots - sgd_slots} slots of frozen parameters are skipped"),
+                              n_slots=sgd_slots)
 
     # per-kernel figures of the other hand-written kernels of the step, each from its own launches' events
     C, K = 128, args.queue
