@@ -16,8 +16,9 @@ the four colour adjustments in their drawn order, grayscale, Gaussian blur, flip
 views are cv2 / albumentations in the reference (loader.py:93-109), neither installed nor pinned: the crop of a uint8
 dataset is resampled in cv2.resize's INTER_LINEAR integer arithmetic as OpenCV's source publishes it (11-bit weights, int32
 horizontal pass, the vertical pass's shifts, the 2 x 2 area special case; oracle/augment_oracle.py cv2_resize_linear_u8) --
-restated from the dependency's source, PARITY-UNPINNED -- and then goes through the same Pillow-arithmetic colour stages
-(albumentations' ColorJitter rides on cv2's colour conversions and LUTs, which are not restated: unpinned as well) and
+restated from the dependency's source, PARITY-UNPINNED -- then goes through A.ColorJitter / A.ToGray in albumentations' own
+arithmetic on cv2 (float64 look-up tables truncated to uint8, cv2's 8-bit RGB2GRAY / RGB2HSV / HSV2RGB, addWeighted: the
+`arithmetic = 1` rows of cp2_color_ops, restated in oracle/augment_oracle.py albu_* / cv2_*, unpinned as well) and
 Pillow's Gaussian blur, which IS what the reference calls for them (loader.py:136-152).
 """
 from __future__ import annotations
@@ -76,18 +77,24 @@ def erase_params(rng: np.random.Generator, n: int, h: int, w: int, scale=(0.5, 0
 
 
 def jitter_table(rng: np.random.Generator, n: int, brightness=0.4, contrast=0.4, saturation=0.4, hue=0.1, p: float = 0.8,
-                 p_gray: float = 0.2) -> np.ndarray:
+                 p_gray: float = 0.2, arithmetic: int = 0) -> np.ndarray:
     """RandomApply([ColorJitter(b, c, s, h)], p) + RandomGrayscale(p_gray) parameters for n samples (torchvision
-    ColorJitter.get_params: a random order of the four adjustments, factors ~ U(1-x, 1+x), hue ~ U(-h, h)), as the int32
-    [n, 12] rows of cp2_color_ops: order[4] (-1 = not applied), float bits of the three factors, uint8(hue * 255), gray."""
+    ColorJitter.get_params / albumentations ColorJitter.get_params: a random order of the four adjustments, factors ~
+    U(1-x, 1+x), hue ~ U(-h, h)), as the int32 [n, 12] rows of cp2_color_ops: order[4] (-1 = not applied), float bits of the
+    three factors, uint8(hue * 255), gray, the arithmetic the kernel applies them in (0: torchvision on PIL images -- the
+    background views, main.py:212-216; 1: albumentations on cv2 -- the foreground views, main.py:236-237), float bits of
+    the hue factor."""
     t = np.zeros((n, 12), dtype=np.int32)
     apply = rng.random(n) < p
     order = rng.permuted(np.tile(np.arange(4, dtype=np.int32), (n, 1)), axis=1)
     t[:, 0:4] = np.where(apply[:, None], order, -1)
     f = np.stack([rng.uniform(1 - x, 1 + x, n) for x in (brightness, contrast, saturation)], 1).astype(np.float32)
     t[:, 4:7] = f.view(np.int32)
-    t[:, 7] = hue_shift_u8(rng.uniform(-hue, hue, n))
+    hf = rng.uniform(-hue, hue, n)
+    t[:, 7] = hue_shift_u8(hf)
     t[:, 8] = rng.random(n) < p_gray
+    t[:, 9] = arithmetic
+    t[:, 10] = hf.astype(np.float32).view(np.int32)
     return t
 
 
@@ -197,6 +204,7 @@ def make_step_batch(ds: DeviceDataset, fg_idx: np.ndarray, bg0_idx: np.ndarray, 
         imgs = torch.cat([fg[0], bg[0]])
     else:
         colour = jitter_table(rng, 4 * n)
+        colour[: 2 * n, 9] = 1                              # foreground views: albumentations-on-cv2 arithmetic (loader.py:93-109)
         blur, rmax = blur_table(rng, 4 * n)
         rects4 = np.concatenate([np.zeros((2 * n, 4), dtype=np.int32), rects])           # foreground views: nothing erased
         parts = [np.concatenate(tabs), colour, blur, rects4]

@@ -149,9 +149,69 @@ __device__ __forceinline__ Rgb hue_shift(Rgb c, int shift) {
     }
 }
 
+// ---- the same four adjustments + grayscale as albumentations runs them on cv2 (the reference's FOREGROUND views,
+// main.py:236-237, loader.py:93-109): LUTs built in float64 and truncated, cv2's 8-bit RGB2GRAY (15-bit fixed point),
+// RGB2HSV (12-bit fixed point, two division tables) / HSV2RGB (float32 sector arithmetic), addWeighted (float32, rounded
+// half to even).  Restated from the published sources of albumentations / OpenCV 4.x, parity-unpinned (neither is in the
+// image); the CPU restatement the tests compare with is oracle/augment_oracle.py (cv2_* / albu_*).
+__device__ __forceinline__ int cv_gray(Rgb c) { return (c.r * 9798 + c.g * 19235 + c.b * 3735 + (1 << 14)) >> 15; }
+__device__ __forceinline__ int lut_trunc(double v) { return v <= 0.0 ? 0 : (v >= 255.0 ? 255 : (int)v); }   // np.clip + astype(uint8)
+__device__ __forceinline__ int cv_round_u8(float v) { return clip8((int)rintf(v)); }                            // saturate_cast<uchar>(float)
+__device__ __forceinline__ int cv_div_table(int num, int den_times, int i) {    // saturate_cast<int>((num << 12) / (den_times * i)): half to even
+    return i == 0 ? 0 : (int)rint((double)(num << 12) / ((double)den_times * (double)i));
+}
+
+__device__ __forceinline__ Rgb cv_hue(Rgb c, double factor) {
+    // RGB2HSV_b, hrange 180
+    const int v = max(c.r, max(c.g, c.b)), vmin = min(c.r, min(c.g, c.b)), diff = v - vmin;
+    const int s = (diff * cv_div_table(255, 1, v) + (1 << 11)) >> 12;
+    int h = v == c.r ? c.g - c.b : (v == c.g ? c.b - c.r + 2 * diff : c.r - c.g + 4 * diff);
+    h = (h * cv_div_table(180, 6, diff) + (1 << 11)) >> 12;          // arithmetic shift
+    if (h < 0) h += 180;
+    h = clip8(h);
+    // albumentations: lut = np.mod(arange(256) + 180 * factor, 180).astype(uint8)
+    double a = fmod((double)h + 180.0 * factor, 180.0);
+    if (a < 0.0) a += 180.0;
+    const int hh = (int)a;
+    // HSV2RGB_b -> HSV2RGB_native on (h, s / 255, v / 255), hscale = 6 / 180
+    const float sf = (float)s * (1.0f / 255.0f), vf = (float)v * (1.0f / 255.0f);
+    if (sf == 0.0f) { const int g = cv_round_u8(vf * 255.0f); return Rgb{g, g, g}; }
+    float hf = fmodf((float)hh * (6.0f / 180.0f), 6.0f);
+    int sector = (int)floorf(hf);
+    hf -= (float)sector;
+    if ((unsigned)sector >= 6u) { sector = 0; hf = 0.0f; }
+    const float tab[4] = {vf, vf * (1.0f - sf), vf * (1.0f - sf * hf), vf * (1.0f - sf * (1.0f - hf))};
+    // sector_data[sector] = tab index of (b, g, r)
+    const int sb[6] = {1, 1, 3, 0, 0, 2}, sg[6] = {3, 0, 0, 2, 1, 1}, sr[6] = {0, 2, 1, 1, 3, 0};
+    return Rgb{cv_round_u8(tab[sr[sector]] * 255.0f), cv_round_u8(tab[sg[sector]] * 255.0f), cv_round_u8(tab[sb[sector]] * 255.0f)};
+}
+
+__device__ __forceinline__ Rgb cv_jitter_op(Rgb c, int op, double fb, double fc, float fsat, double fhue, double mean) {
+    if (op == 0) {
+        if (fb == 1.0) return c;
+        return Rgb{lut_trunc((double)c.r * fb), lut_trunc((double)c.g * fb), lut_trunc((double)c.b * fb)};
+    }
+    if (op == 1) {
+        if (fc == 1.0) return c;
+        if (fc == 0.0) { const int m = (int)(mean + 0.5); return Rgb{m, m, m}; }
+        const double off = mean * (1.0 - fc);
+        return Rgb{lut_trunc((double)c.r * fc + off), lut_trunc((double)c.g * fc + off), lut_trunc((double)c.b * fc + off)};
+    }
+    if (op == 2) {
+        if (fsat == 1.0f) return c;
+        const int g = cv_gray(c);
+        if (fsat == 0.0f) return Rgb{g, g, g};
+        const float beta = (float)(1.0 - (double)fsat), gb = (float)g * beta;   // albumentations passes 1 - factor (float64) to cv2
+        return Rgb{cv_round_u8((float)c.r * fsat + gb), cv_round_u8((float)c.g * fsat + gb), cv_round_u8((float)c.b * fsat + gb)};
+    }
+    if (op == 3) return fhue == 0.0 ? c : cv_hue(c, fhue);
+    return c;
+}
+
 // params row (int32 [CP2_COLOR_PARAMS = 12]): [0..3] the adjustments in application order (0 brightness, 1 contrast,
 // 2 saturation, 3 hue, -1 none), [4..6] float bits of the brightness / contrast / saturation factors, [7] hue shift
-// (uint8(hue_factor * 255)), [8] grayscale flag, [9..11] reserved.
+// (uint8(hue_factor * 255)), [8] grayscale flag, [9] arithmetic: 0 = Pillow (torchvision on PIL images: the background
+// views), 1 = albumentations on cv2 (the foreground views), [10] float bits of the hue factor (arithmetic 1), [11] reserved.
 // phase 0: every adjustment in front of the contrast one (all of them when there is none, then grayscale), and the sum
 //          of the L values contrast needs (ImageStat over img.convert("L")) into lsum[b];
 // phase 1: samples with a contrast adjustment only -- contrast and whatever follows it, then grayscale.
@@ -166,15 +226,23 @@ __global__ __launch_bounds__(256) void color_kernel(uint32_t* __restrict__ img, 
     const int first = phase == 0 ? 0 : cpos, last = phase == 0 ? cpos : 4;
     const float fb = __int_as_float(p[4]), fc = __int_as_float(p[5]), fsat = __int_as_float(p[6]);
     const int shift = p[7] & 255, gray = p[8];
+    const bool cv = p[9] == 1;
+    const double fhue = (double)__int_as_float(p[10]);
     int mean = 0;
-    if (phase == 1) mean = (int)((double)lsum[b] / (double)HW + 0.5);      // int(stat.mean[0] + 0.5)
+    double cvmean = 0.0;
+    if (phase == 1) {
+        cvmean = (double)lsum[b] / (double)HW;                             // float64 mean of the gray image
+        mean = (int)(cvmean + 0.5);                                        // int(stat.mean[0] + 0.5)
+    }
     unsigned long long local = 0;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < HW; e += gridDim.x * 256) {
         const uint32_t v = img[(int64_t)b * HW + e];
         Rgb c{(int)(v & 255), (int)((v >> 8) & 255), (int)((v >> 16) & 255)};
         for (int k = first; k < last; ++k) {
             const int op = p[k];
-            if (op == 0) {
+            if (cv) {
+                c = cv_jitter_op(c, op, (double)fb, (double)fc, fsat, fhue, cvmean);
+            } else if (op == 0) {
                 const bool clip = !(fb >= 0.0f && fb <= 1.0f);
                 c = Rgb{blend1(0, c.r, fb, clip), blend1(0, c.g, fb, clip), blend1(0, c.b, fb, clip)};
             } else if (op == 1) {
@@ -188,9 +256,9 @@ __global__ __launch_bounds__(256) void color_kernel(uint32_t* __restrict__ img, 
                 c = hue_shift(c, shift);
             }
         }
-        if (phase == 0 && cpos < 4) local += (unsigned long long)rgb2l(c);
+        if (phase == 0 && cpos < 4) local += (unsigned long long)(cv ? cv_gray(c) : rgb2l(c));
         if (gray && (phase == 1 || cpos == 4)) {
-            const int l = rgb2l(c);
+            const int l = cv ? cv_gray(c) : rgb2l(c);
             c = Rgb{l, l, l};
         }
         img[(int64_t)b * HW + e] = (uint32_t)c.r | ((uint32_t)c.g << 8) | ((uint32_t)c.b << 16);

@@ -15,7 +15,8 @@ third-party image libraries that are not part of /root/reference:
     BoxBlur.c (Gaussian = three box passes per axis, 24-bit weights).  This file restates those published algorithms in
     numpy, and tests/test_augment_photometric.py / make_augment_goldens.py pin the restatement against Pillow itself.
   * foreground views: albumentations on cv2 (RandomResizedCrop = cv2.resize INTER_LINEAR, ColorJitter / ToGray by cv2
-    LUTs) -- cv2 and albumentations are absent here, so that arithmetic stays **parity-unpinned**; only the foreground's
+    colour conversions, LUTs and addWeighted) -- cv2 and albumentations are absent here, so that arithmetic is restated
+    from the dependencies' published sources (cv2_* / albu_* below) and stays **parity-unpinned**; only the foreground's
     Gaussian blur is Pillow's (loader.py:136-152, the same ImageFilter.GaussianBlur).
 """
 from __future__ import annotations
@@ -249,6 +250,138 @@ def color_jitter(img: np.ndarray, order, factors) -> np.ndarray:
     for k in order:
         img = JITTER_OPS[int(k)](img, float(factors[int(k)]))
     return img
+
+
+# --------------------------------------------------------------------------- foreground views: albumentations on cv2
+# A.ColorJitter(0.4, 0.4, 0.4, 0.1, p=0.8) and A.ToGray(p=0.2) of main.py:236-237 on uint8 RGB images.  albumentations
+# (functional.py: adjust_{brightness,contrast,saturation,hue}_torchvision, their *_uint8 helpers, to_gray) and OpenCV 4.x
+# (imgproc color_rgb.simd.hpp RGB2Gray<uchar>, color_hsv.simd.hpp RGB2HSV_b / HSV2RGB_b / HSV2RGB_native, core arithm
+# addWeighted, LUT) are absent from /root/reference and from this image: restated from the dependencies' published
+# sources, PARITY-UNPINNED.  What is restated:
+#   * brightness:  lut[i] = uint8(clip(i * f, 0, 255))  (astype truncates), cv2.LUT;
+#   * contrast:    mean = float64 mean of cv2 RGB2GRAY(img); lut[i] = uint8(clip(i * f + mean * (1 - f), 0, 255)), cv2.LUT;
+#   * saturation:  gray = RGB2GRAY -> GRAY2RGB; cv2.addWeighted(img, f, gray, 1 - f, 0): float32 a * alpha + b * beta + gamma,
+#                  saturate_cast<uchar> = round half to even, clamped;
+#   * hue:         RGB2HSV (8 bit: H in [0, 180)), H through lut[i] = uint8(mod(i + 180 f, 180)), HSV2RGB;
+#   * RGB2GRAY 8 bit: (R * 9798 + G * 19235 + B * 3735 + 2^14) >> 15;
+#   * RGB2HSV 8 bit: 12-bit fixed point with the two division tables (255 << 12) / v and (180 << 12) / (6 diff), rounded
+#     half to even; HSV2RGB 8 bit: float32 sector arithmetic of HSV2RGB_native on (H, S / 255, V / 255), * 255, rounded.
+def cv2_rgb2gray_u8(img: np.ndarray) -> np.ndarray:
+    """(..., 3) uint8 RGB -> (...) uint8 as cv2.cvtColor(img, cv2.COLOR_RGB2GRAY)."""
+    v = img.astype(np.int64)
+    return ((v[..., 0] * 9798 + v[..., 1] * 19235 + v[..., 2] * 3735 + (1 << 14)) >> 15).astype(np.uint8)
+
+
+_HSV_SHIFT = 12
+_SDIV = np.zeros(256, dtype=np.int64)
+_HDIV180 = np.zeros(256, dtype=np.int64)
+_SDIV[1:] = np.rint((255 << _HSV_SHIFT) / (1.0 * np.arange(1, 256))).astype(np.int64)       # saturate_cast<int>(double): half to even
+_HDIV180[1:] = np.rint((180 << _HSV_SHIFT) / (6.0 * np.arange(1, 256))).astype(np.int64)
+
+
+def cv2_rgb2hsv_u8(img: np.ndarray) -> np.ndarray:
+    """(..., 3) uint8 RGB -> (..., 3) uint8 (H in [0, 180), S, V) as cv2.cvtColor(img, cv2.COLOR_RGB2HSV) (RGB2HSV_b)."""
+    v3 = img.astype(np.int64)
+    r, g, b = v3[..., 0], v3[..., 1], v3[..., 2]
+    v = np.maximum(np.maximum(r, g), b)
+    diff = v - np.minimum(np.minimum(r, g), b)
+    vr, vg = v == r, v == g
+    s = (diff * _SDIV[v] + (1 << (_HSV_SHIFT - 1))) >> _HSV_SHIFT
+    h = np.where(vr, g - b, np.where(vg, b - r + 2 * diff, r - g + 4 * diff))
+    h = (h * _HDIV180[diff] + (1 << (_HSV_SHIFT - 1))) >> _HSV_SHIFT                        # arithmetic shift (floor), as in C
+    h = h + np.where(h < 0, 180, 0)
+    return np.stack([np.clip(h, 0, 255), s, v], -1).astype(np.uint8)
+
+
+_SECTOR = np.array([[1, 3, 0], [1, 0, 2], [3, 0, 1], [0, 2, 1], [0, 1, 3], [2, 1, 0]])      # tab index of (b, g, r) per sector
+
+
+def cv2_hsv2rgb_u8(img: np.ndarray) -> np.ndarray:
+    """(..., 3) uint8 (H, S, V) -> (..., 3) uint8 RGB as cv2.cvtColor(img, cv2.COLOR_HSV2RGB) (HSV2RGB_b, hrange 180)."""
+    f32 = np.float32
+    h = img[..., 0].astype(f32)
+    s = img[..., 1].astype(f32) * f32(1.0 / 255.0)
+    v = img[..., 2].astype(f32) * f32(1.0 / 255.0)
+    h = np.fmod(h * f32(6.0 / 180.0), f32(6.0)).astype(f32)
+    sector = np.floor(h).astype(np.int64)
+    h = (h - sector.astype(f32)).astype(f32)
+    bad = (sector < 0) | (sector >= 6)
+    sector = np.where(bad, 0, sector)
+    h = np.where(bad, f32(0), h).astype(f32)
+    one = f32(1.0)
+    tab = np.stack([v, v * (one - s), v * (one - s * h), v * (one - s * (one - h))], -1).astype(f32)
+    idx = _SECTOR[sector]                                                                   # (..., 3): b, g, r
+    bgr = np.take_along_axis(tab, idx, -1)
+    bgr = np.where((s == 0)[..., None], v[..., None], bgr).astype(f32)
+    out = np.clip(np.rint(bgr * f32(255.0)), 0, 255).astype(np.uint8)                       # saturate_cast<uchar>(float): half to even
+    return out[..., ::-1]                                                                   # -> r, g, b
+
+
+def cv2_add_weighted_u8(a: np.ndarray, alpha: float, b: np.ndarray, beta: float, gamma: float = 0.0) -> np.ndarray:
+    f32 = np.float32
+    t = a.astype(f32) * f32(alpha) + b.astype(f32) * f32(beta) + f32(gamma)
+    return np.clip(np.rint(t), 0, 255).astype(np.uint8)
+
+
+def _lut_u8(values: np.ndarray) -> np.ndarray:
+    return np.clip(values, 0, 255).astype(np.uint8)                                         # albumentations clip(): np.clip + astype (truncation)
+
+
+def albu_adjust_brightness(img: np.ndarray, factor: float) -> np.ndarray:
+    if factor == 0:
+        return np.zeros_like(img)
+    if factor == 1:
+        return img
+    return _lut_u8(np.arange(0, 256) * factor)[img]
+
+
+def albu_contrast_mean(img: np.ndarray) -> float:
+    return float(cv2_rgb2gray_u8(img).mean())
+
+
+def albu_adjust_contrast(img: np.ndarray, factor: float) -> np.ndarray:
+    if factor == 1:
+        return img
+    mean = albu_contrast_mean(img)
+    if factor == 0:
+        return np.full_like(img, int(mean + 0.5))
+    return _lut_u8(np.arange(0, 256) * factor + mean * (1 - factor))[img]
+
+
+def albu_adjust_saturation(img: np.ndarray, factor: float) -> np.ndarray:
+    if factor == 1:
+        return img
+    gray = np.repeat(cv2_rgb2gray_u8(img)[..., None], 3, -1)
+    if factor == 0:
+        return gray
+    return cv2_add_weighted_u8(img, factor, gray, 1 - factor, 0.0)
+
+
+def albu_hue_lut(factor: float) -> np.ndarray:
+    return np.mod(np.arange(0, 256, dtype=np.int16) + 180 * factor, 180).astype(np.uint8)
+
+
+def albu_adjust_hue(img: np.ndarray, factor: float) -> np.ndarray:
+    if factor == 0:
+        return img
+    hsv = cv2_rgb2hsv_u8(img)
+    hsv[..., 0] = albu_hue_lut(factor)[hsv[..., 0]]
+    return cv2_hsv2rgb_u8(hsv)
+
+
+ALBU_JITTER_OPS = (albu_adjust_brightness, albu_adjust_contrast, albu_adjust_saturation, albu_adjust_hue)
+
+
+def albu_color_jitter(img: np.ndarray, order, factors) -> np.ndarray:
+    """A.ColorJitter.apply: the four adjustments in the drawn order; factors = (brightness, contrast, saturation, hue)."""
+    for k in order:
+        img = ALBU_JITTER_OPS[int(k)](img, float(factors[int(k)]))
+    return img
+
+
+def albu_to_gray(img: np.ndarray) -> np.ndarray:
+    """A.ToGray: cv2 RGB2GRAY then GRAY2RGB."""
+    return np.repeat(cv2_rgb2gray_u8(img)[..., None], 3, -1)
 
 
 # --------------------------------------------------------------------------- BoxBlur.c

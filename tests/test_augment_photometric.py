@@ -112,14 +112,53 @@ def _unpack(t):
     return np.stack([x & 255, (x >> 8) & 255, (x >> 16) & 255], -1).astype(np.uint8)
 
 
-def _colour_row(order=(), factors=(1.0, 1.0, 1.0), hue=0.0, gray=False):
+def _colour_row(order=(), factors=(1.0, 1.0, 1.0), hue=0.0, gray=False, arithmetic=0):
     row = np.zeros(12, dtype=np.int32)
     row[:4] = -1
     row[:len(order)] = order
     row[4:7] = np.asarray(factors, dtype=np.float32).view(np.int32)
     row[7] = A.hue_shift_u8(hue)
     row[8] = int(gray)
+    row[9] = arithmetic
+    row[10] = np.asarray([hue], dtype=np.float32).view(np.int32)[0]
     return row
+
+
+def test_cv2_colour_restatement_known_answers():
+    """The restatement of OpenCV's 8-bit colour conversions and of albumentations' ColorJitter helpers (the reference's
+    foreground views, main.py:236-237; neither library is in the image: PARITY-UNPINNED) on values that follow from the
+    published definitions: the primaries' hue sextants (H = 0, 30, ..., 150 on cv2's 0..179 scale, S = V = 255), gray
+    levels with S = 0, Y = 0.299 R + 0.587 G + 0.114 B in 15-bit fixed point, exact HSV round trips of saturated colours,
+    albumentations' look-up tables, the identity cases of every adjustment."""
+    px = lambda *c: np.array([[c]], dtype=np.uint8)                                   # noqa: E731
+    assert [int(P.cv2_rgb2gray_u8(px(*c))[0, 0]) for c in ((255, 0, 0), (0, 255, 0), (0, 0, 255), (255, 255, 255), (0, 0, 0))] == [76, 150, 29, 255, 0]
+    sext = {(255, 0, 0): 0, (255, 255, 0): 30, (0, 255, 0): 60, (0, 255, 255): 90, (0, 0, 255): 120, (255, 0, 255): 150}
+    for rgb, h in sext.items():
+        hsv = P.cv2_rgb2hsv_u8(px(*rgb))
+        assert hsv[0, 0].tolist() == [h, 255, 255]
+        assert P.cv2_hsv2rgb_u8(hsv)[0, 0].tolist() == list(rgb)
+    for g in (0, 1, 77, 128, 255):
+        assert P.cv2_rgb2hsv_u8(px(g, g, g))[0, 0].tolist() == [0, 0, g]
+        assert P.cv2_hsv2rgb_u8(np.array([[[37, 0, g]]], dtype=np.uint8))[0, 0].tolist() == [g, g, g]
+    # S = 127.5 exactly; the table entry round(255 * 4096 / 200) = 5222 is a little low: (100 * 5222 + 2048) >> 12 = 127
+    assert P.cv2_rgb2hsv_u8(px(200, 100, 100))[0, 0].tolist() == [0, 127, 200]
+    assert P.cv2_rgb2hsv_u8(px(100, 100, 200))[0, 0, 0] == 120 and P.cv2_rgb2hsv_u8(px(100, 200, 150))[0, 0, 0] == 75
+    # albumentations' tables: truncation, python-style modulo
+    assert P.albu_hue_lut(0.1)[[0, 161, 162, 179]].tolist() == [18, 179, 0, 17]
+    assert P.albu_hue_lut(-0.05)[[0, 8, 9, 179]].tolist() == [171, 179, 0, 170]
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (16, 16, 3), dtype=np.uint8)
+    assert P.albu_adjust_brightness(img, 1.3).max() == 255 and np.array_equal(P.albu_adjust_brightness(img, 0.5), (img * 0.5).astype(np.uint8))
+    for op in P.ALBU_JITTER_OPS[:3]:
+        assert np.array_equal(op(img, 1), img)
+    assert np.array_equal(P.albu_adjust_hue(img, 0), img)
+    assert np.array_equal(P.albu_adjust_saturation(img, 0), P.albu_to_gray(img))
+    m = P.albu_contrast_mean(img)
+    assert np.array_equal(P.albu_adjust_contrast(img, 0), np.full_like(img, int(m + 0.5)))
+    assert np.array_equal(P.albu_adjust_contrast(img, 0.5), np.clip(img * 0.5 + m * 0.5, 0, 255).astype(np.uint8))
+    # the round trip through cv2's 8-bit HSV is lossy by a few levels, never more (180 hue steps, 8-bit S)
+    rt = P.cv2_hsv2rgb_u8(P.cv2_rgb2hsv_u8(img))
+    assert np.abs(rt.astype(int) - img.astype(int)).max() <= 6
 
 
 def _blur_row(sigma):
@@ -192,6 +231,63 @@ def test_hue_kernel_over_all_colours_and_shifts():
         got = _unpack(x)
         for b in range(0, 16, 5):
             assert np.array_equal(got[b], P.adjust_hue(allc[b], hue)), (hue, b)
+
+
+@pytest.mark.gpu
+def test_cv2_arithmetic_kernel_over_all_colours():
+    """The `arithmetic = 1` rows of cp2_color_ops (albumentations' ColorJitter / ToGray on cv2's 8-bit conversions: the
+    foreground views) against the oracle's restatement for every one of the 2^24 colours: hue at several factors, saturation,
+    brightness, grayscale; contrast (needs the image mean) on whole images below."""
+    from cp2_amd import ops
+    v = np.arange(256, dtype=np.uint8)
+    allc = np.stack(np.meshgrid(v, v, v, indexing="ij"), -1).reshape(16, 1024, 1024, 3)
+    packed = torch.from_numpy(_pack(allc)).cuda()
+    cases = [((3,), dict(hue=h), lambda im, h=h: P.albu_adjust_hue(im, float(np.float32(h)))) for h in (0.1, -0.1, 0.037, -0.0625)]
+    cases += [((2,), dict(factors=(1.0, 1.0, f)), lambda im, f=f: P.albu_adjust_saturation(im, float(np.float32(f)))) for f in (0.6, 1.37)]
+    cases += [((0,), dict(factors=(f, 1.0, 1.0)), lambda im, f=f: P.albu_adjust_brightness(im, float(np.float32(f)))) for f in (0.61, 1.4)]
+    cases += [((), dict(gray=True), P.albu_to_gray)]
+    for order, kw, fn in cases:
+        x = packed.clone()
+        ops.color_ops(x, torch.from_numpy(np.stack([_colour_row(order, arithmetic=1, **kw)] * 16)).cuda())
+        got = _unpack(x)
+        for b in range(0, 16, 5):
+            assert np.array_equal(got[b], fn(allc[b])), (order, kw, b)
+
+
+@pytest.mark.gpu
+def test_cv2_arithmetic_kernel_on_images_in_every_order():
+    """Whole images through the albumentations-on-cv2 rows: all four adjustments in drawn orders (contrast first / in the
+    middle / last: its mean is the float64 mean of cv2's gray image AT THAT POINT), with and without ToGray, beside
+    Pillow-arithmetic rows in the same launch."""
+    from cp2_amd import ops
+    rng = np.random.default_rng(21)
+    B, H, W = 10, 96, 80
+    imgs = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    imgs[:4] = np.stack([P.gaussian_blur(s, 2.0) for s in imgs[:4]])
+    colour = A.jitter_table(rng, B, p=1.0, p_gray=0.3, arithmetic=1)
+    colour[0, :4] = (1, 3, 0, 2)
+    colour[1, :4] = (0, 2, 3, 1)
+    colour[2, :4] = (3, 1, 2, 0)
+    colour[3, :4] = -1
+    colour[8:, 9] = 0                                                                   # two Pillow rows in the same call
+    x = torch.from_numpy(_pack(imgs)).cuda()
+    ops.color_ops(x, torch.from_numpy(colour).cuda())
+    got = _unpack(x)
+    for b in range(B):
+        order = [int(k) for k in colour[b, :4] if k >= 0]
+        f = colour[b, 4:7].copy().view(np.float32)
+        if colour[b, 9] == 1:
+            hue = float(colour[b, 10:11].copy().view(np.float32)[0])
+            want = P.albu_color_jitter(imgs[b], order, (float(f[0]), float(f[1]), float(f[2]), hue))
+            if colour[b, 8]:
+                want = P.albu_to_gray(want)
+        else:
+            want = imgs[b]
+            for k in order:
+                want = P.adjust_hue_shift(want, int(colour[b, 7])) if k == 3 else P.JITTER_OPS[k](want, float(f[k]))
+            if colour[b, 8]:
+                want = P.to_grayscale3(want)
+        assert np.array_equal(got[b], want), (b, order, int(colour[b, 9]))
 
 
 @pytest.mark.gpu
