@@ -356,7 +356,10 @@ int cp2_pil_resize_crop(const unsigned char* src, int N, int Hs, int Ws, const i
 /* cp2_color_ops: ColorJitter + RandomGrayscale in place (Pillow ImageEnhance / Blend.c / Convert.c arithmetic).
  * params: int32 [B,CP2_COLOR_PARAMS]: [0..3] adjustments in application order (0 brightness, 1 contrast, 2 saturation,
  * 3 hue, -1 none), [4..6] float bits of the brightness / contrast / saturation factors, [7] uint8(hue_factor*255),
- * [8] grayscale flag.  lsum: uint64 [B] scratch (zeroed by the call; receives the L sum the contrast step needs). */
+ * [8] grayscale flag, [9] arithmetic: 0 = torchvision on PIL images (the reference's background views), 1 = albumentations
+ * on cv2 (its foreground views, main.py:236-237: float64 look-up tables truncated to uint8, cv2's 8-bit RGB2GRAY / RGB2HSV /
+ * HSV2RGB, addWeighted; restated from the published sources), [10] float bits of the hue factor (arithmetic 1).
+ * lsum: uint64 [B] scratch (zeroed by the call; receives the gray sum the contrast step needs). */
 #define CP2_COLOR_PARAMS 12
 int cp2_color_ops(uint32_t* img_rgbx, const int32_t* params, uint64_t* lsum, int B, int H, int W, void* stream);
 /* cp2_blur_to_tensor: ImageFilter.GaussianBlur(sigma) (Pillow BoxBlur.c: three box passes per axis, 24-bit weights,
