@@ -325,7 +325,7 @@ def main():
 
     def timed_region(n_steps, timed_kernels):
         if world > 1:
-            dist.barrier()
+            cdist.barrier("bench: barrier in front of the timed region")
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         last = None
@@ -335,13 +335,13 @@ def main():
         host_issue[0] = (time.perf_counter() - t0) / n_steps * 1e3      # host time to ENQUEUE a step (no device wait inside)
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            cdist.barrier("bench: barrier behind the timed region")
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         local_dt[0] = dt
         if world > 1:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            cdist.tracked("bench: max over the ranks of the region's time", dist.all_reduce(t, op=dist.ReduceOp.MAX, async_op=True))
             dt = float(t)
         return dt, last
 
@@ -349,6 +349,8 @@ def main():
         cdist.progress(i)
         one_step(i, False)
     torch.cuda.synchronize()
+    if args.warmup >= 2:
+        cdist.steady()       # every kernel has run on this rank: from here on a collective pending for --timeout seconds is a hang
     # --overlap auto with peers: north_star asks for the key branch's exchange steps on a side HIP stream; with ONE rank the
     # fork / join measured slower than the ~0.14 ms it hides -- but a one-rank rehearsal moves no bytes.
     # So with real peers both forms are timed here, after the warm-up, and the faster one (MAX over the ranks) is used.

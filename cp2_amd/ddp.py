@@ -217,11 +217,11 @@ class FlatDDP(torch.nn.Module):
     def _broadcast_state(self) -> None:
         """Rank 0's parameters and buffers everywhere, as DDP's constructor does."""
         m = self.module
-        dist.broadcast(m._flat_q, src=0)
-        dist.broadcast(m._flat_k, src=0)
-        for b in m.buffers():
+        cdist.tracked("FlatDDP: broadcast of rank 0's query parameters", dist.broadcast(m._flat_q, src=0, async_op=True))
+        cdist.tracked("FlatDDP: broadcast of rank 0's key parameters", dist.broadcast(m._flat_k, src=0, async_op=True))
+        for n, b in m.named_buffers():
             if b.numel():
-                dist.broadcast(b, src=0)
+                cdist.tracked(f"FlatDDP: broadcast of buffer {n}", dist.broadcast(b, src=0, async_op=True))
         if getattr(m, "_flat_k_bf16", None) is not None:
             m._flat_k_bf16.copy_(m._flat_k)
         if getattr(m, "_flat_q_bf16", None) is not None:

@@ -42,21 +42,43 @@ def multi() -> bool:
 
 
 def init_process_group(backend: str, rank: int, world: int, init_method: Optional[str] = None,
-                       timeout_s: float = DEFAULT_TIMEOUT_S, watchdog: bool = True) -> None:
+                       timeout_s: float = DEFAULT_TIMEOUT_S, watchdog: bool = True,
+                       startup_timeout_s: Optional[float] = None) -> None:
     """The ONE place the package creates its process group (cp2_amd.main, bench.py, the multi-process tests):
       * HSA_ENABLE_IPC_MODE_LEGACY=0 -- the dmabuf IPC path; with the legacy mode RCCL's peer-memory set-up fails on this
         driver stack (hipIpcGetMemHandle: invalid argument), so it must be in the environment before the first HIP call of
         a multi-process run, not only in bench.py;
       * a bounded timeout (torch's nccl default is 10 minutes): a collective that never completes ends the process;
-      * the hang watchdog below, which says WHICH exchange step did not complete before that happens."""
+      * the hang watchdog below, which says WHICH exchange step did not complete before that happens.
+    Two limits: until the caller declares the run steady (`steady()`, after the warm-up steps) a collective may stay pending
+    for `startup_timeout_s` (default max(480 s, 4 x timeout_s)): the first steps run MIOpen's solver search, which takes
+    15 s on an idle one-GPU box and several times that when W ranks share a host and its solver database, and it does not
+    take the same time on every rank -- a peer that is still searching is not a hang (found by a 4-ranks-on-one-GPU rehearsal
+    of bench.py that the 120 s limit killed during its first step).  From `steady()` on the limit is `timeout_s`."""
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    kw = dict(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
+    startup = max(480.0, 4.0 * timeout_s) if startup_timeout_s is None else float(startup_timeout_s)
+    startup = max(startup, timeout_s)
+    kw = dict(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=startup))
     if init_method:
         kw["init_method"] = init_method
     dist.init_process_group(**kw)
     COLLECTIVES.clear()
+    _LIMITS[:] = [0.8 * startup, 0.8 * timeout_s, float(timeout_s), False]
     if watchdog and world > 1:
-        start_watchdog(0.8 * timeout_s)
+        start_watchdog(0.8 * timeout_s, startup_s=0.8 * startup)
+
+
+def steady() -> None:
+    """The warm-up is over (every kernel of the step has run once on every rank): from now on a collective that stays
+    pending longer than the steady-state limit is a hang.  Also lowers the process group's own timeout to that limit."""
+    if _LIMITS[3] or not is_dist():
+        return
+    _LIMITS[3] = True
+    try:
+        from torch.distributed.distributed_c10d import _set_pg_timeout
+        _set_pg_timeout(datetime.timedelta(seconds=_LIMITS[2]))
+    except Exception:                               # noqa: BLE001 -- an older torch / a backend without it: the start-up limit stays
+        pass
 
 
 # ---------------------------------------------------------------- which collective hangs?
@@ -74,14 +96,15 @@ class _CollectiveLog:
         self.step = 0
 
     def note(self, name: str, work=None):
-        self.items.append((self.step, name, work))
+        self.items.append((self.step, name, work, time.monotonic()))
         return work
 
     def first_incomplete(self):
-        for step, name, work in self.items:
+        """(step, name, seconds since it was enqueued) of the oldest tracked collective that has not completed, or None."""
+        for step, name, work, t0 in list(self.items):
             try:
                 if work is not None and not work.is_completed():
-                    return step, name
+                    return step, name, time.monotonic() - t0
             except Exception:                       # noqa: BLE001 -- a backend without is_completed()
                 continue
         return None
@@ -90,7 +113,7 @@ class _CollectiveLog:
         inc = self.first_incomplete()
         last = self.items[-1] if self.items else None
         if inc is not None:
-            return f"first collective not completed: {inc[1]} (step {inc[0]})"
+            return f"first collective not completed: {inc[1]} (step {inc[0]}), pending for {inc[2]:.0f} s"
         if last is not None:
             return f"every tracked collective completed; last one enqueued: {last[1]} (step {last[0]})"
         return "no collective was enqueued yet"
@@ -98,6 +121,7 @@ class _CollectiveLog:
 
 COLLECTIVES = _CollectiveLog()
 _PROGRESS = [time.monotonic(), 0]
+_LIMITS = [0.8 * 480.0, 0.8 * DEFAULT_TIMEOUT_S, DEFAULT_TIMEOUT_S, False]   # watchdog: start-up, steady; pg steady timeout; steady?
 _WATCHDOG: Optional[threading.Thread] = None
 HANG_EXIT_CODE = 3
 
@@ -109,20 +133,26 @@ def progress(step: Optional[int] = None) -> None:
         _PROGRESS[1] = COLLECTIVES.step = step
 
 
-def start_watchdog(timeout_s: float, poll_s: float = 2.0, on_hang: Optional[Callable[[str], None]] = None) -> None:
-    """A daemon thread: no progress() for `timeout_s` seconds -> print which exchange step did not complete and end the
-    process with HANG_EXIT_CODE (the host thread may be blocked inside a HIP call by then; a blocked call releases the GIL).
-    Runs before the process group's own timeout so that the named message comes first."""
+def start_watchdog(timeout_s: float, poll_s: float = 2.0, on_hang: Optional[Callable[[str], None]] = None,
+                   startup_s: Optional[float] = None) -> None:
+    """A daemon thread: a tracked collective that stays PENDING longer than the limit -> print which exchange step it is and
+    end the process with HANG_EXIT_CODE (the host thread may be blocked inside a HIP call by then; a blocked call releases
+    the GIL).  The limit is `startup_s` (default: `timeout_s`) until steady() is called, `timeout_s` afterwards; both run out
+    before the process group's own timeout so that the named message comes first.  A process that is merely busy or idle on
+    its host (solver search, a checkpoint, data loading, an epoch's validation) has no pending collective and is left alone."""
     global _WATCHDOG
     if _WATCHDOG is not None:
         return
     progress()
+    _LIMITS[0], _LIMITS[1] = (timeout_s if startup_s is None else startup_s), timeout_s
 
     def run():
         while True:
             time.sleep(poll_s)
-            idle = time.monotonic() - _PROGRESS[0]
-            if idle > timeout_s:
+            inc = COLLECTIVES.first_incomplete()
+            limit = _LIMITS[1] if _LIMITS[3] else _LIMITS[0]
+            if inc is not None and inc[2] > limit:
+                idle = time.monotonic() - _PROGRESS[0]
                 msg = (f"cp2_amd: rank {rank()} of {world_size()} made no progress for {idle:.0f} s at step {_PROGRESS[1]}; "
                        + COLLECTIVES.describe())
                 if on_hang is not None:
@@ -135,6 +165,20 @@ def start_watchdog(timeout_s: float, poll_s: float = 2.0, on_hang: Optional[Call
     _WATCHDOG.start()
 
 
+def tracked(name: str, work):
+    """Register an asynchronous collective with the hang log and wait for it: `tracked("...", dist.broadcast(t, 0, async_op=True))`
+    is a blocking call whose name the watchdog can print."""
+    COLLECTIVES.note(name, work)
+    if work is not None:
+        work.wait()
+    return work
+
+
+def barrier(name: str = "barrier") -> None:
+    if is_dist():
+        tracked(name, dist.barrier(async_op=True))
+
+
 def assert_same_on_all_ranks(what: str, value: int, device=None) -> None:
     """Every rank must hold the same `value` (a hash of something all ranks derive independently, e.g. FlatDDP's bucket
     table): one small all-gather, RuntimeError naming the ranks that differ."""
@@ -143,7 +187,7 @@ def assert_same_on_all_ranks(what: str, value: int, device=None) -> None:
     on_dev = dist.get_backend() != "gloo" and device is not None
     mine = torch.tensor([value & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64, device=device if on_dev else "cpu")
     out = [torch.empty_like(mine) for _ in range(world_size())]
-    dist.all_gather(out, mine)
+    tracked(f"agreement check: {what}", dist.all_gather(out, mine, async_op=True))
     vals = [int(t) for t in out]
     if len(set(vals)) != 1:
         odd = [r for r, v in enumerate(vals) if v != vals[0]]

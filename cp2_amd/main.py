@@ -262,6 +262,8 @@ def main_worker(rank, args):
             if args.same_foreground:
                 batch["img_b"], batch["pixel_ids_b"], batch["region_ids_b"] = batch["img_a"], batch["pixel_ids_a"], batch["region_ids_a"]
             cdist.progress(step)
+            if step == 2:
+                cdist.steady()                  # the solver searches of the first steps are over: the steady-state hang limit applies
             loss = runner(batch)
             seen += per_gpu * world
             if i % args.print_freq == 0 and rank == 0:

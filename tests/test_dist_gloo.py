@@ -127,6 +127,40 @@ def test_watchdog_names_the_collective_that_did_not_complete(tmp_path):
     assert "first collective not completed: c3_key_unshuffle (step 1)" in text
 
 
+def test_watchdog_leaves_a_busy_host_alone_and_knows_start_up_from_steady_state():
+    """What the watchdog judges is a PENDING collective, not the time since the last step: a rank that spends minutes in
+    MIOpen's solver search, a checkpoint or validation has nothing pending and must not be shot (a 4-ranks-on-one-GPU
+    rehearsal of bench.py died in its first step under the old "no progress for 96 s" rule); and a collective may stay
+    pending longer during start-up (peers still searching) than in steady state."""
+    import time
+
+    class Pending:
+        def is_completed(self):
+            return False
+
+    msgs = []
+    cdist.COLLECTIVES.clear()
+    cdist._WATCHDOG = None
+    cdist._LIMITS[3] = False
+    try:
+        cdist.start_watchdog(0.6, poll_s=0.1, on_hang=msgs.append, startup_s=30.0)
+        cdist.progress(0)
+        time.sleep(1.5)                                    # "no progress" for 2.5 x the steady limit, nothing pending
+        assert not msgs
+        cdist.COLLECTIVES.note("c1 all-to-all of the shuffled rows", Pending())
+        time.sleep(1.5)                                    # pending beyond the steady limit, but the run is still starting up
+        assert not msgs
+        cdist._LIMITS[3] = True                            # what steady() sets (it also lowers the group's timeout: none here)
+        t0 = time.time()
+        while not msgs and time.time() - t0 < 5:
+            time.sleep(0.05)
+        assert msgs and "first collective not completed: c1 all-to-all of the shuffled rows (step 0), pending for" in msgs[0]
+    finally:
+        cdist.COLLECTIVES.clear()
+        cdist._WATCHDOG = None
+        cdist._LIMITS[3] = False
+
+
 def test_shuffle_plan_refuses_a_table_that_is_no_permutation():
     with pytest.raises(ValueError, match="not a permutation"):
         cdist.ShufflePlan(torch.tensor([0, 1, 1, 3]), 0, 2)
