@@ -65,7 +65,13 @@ def _worker(rank, port, out_dir, grad_sync):
         opt = FlatSGD(ddp, 0.01, momentum=0.9, weight_decay=1e-4)
         assert model.overlap_key_branch is None               # -> one stream, what every world size selects by default
         losses = []
+        cdist.barrier("test: asynchronous barrier over RCCL")     # the tracked forms bench.py uses around its timed region
+        cdist.assert_same_on_all_ranks("test value", 12345, dev)
         for step in range(4):
+            cdist.progress(step)
+            if step == 2:
+                cdist.steady()                                    # start-up limit -> steady limit (_set_pg_timeout on the RCCL group)
+                assert cdist._LIMITS[3] and cdist.COLLECTIVES.first_incomplete() is None
             batch = synthetic.make_batch(6, 64, 64, dev, seed=step)
             loss = ddp(visualize=False, step=step, new_epoch=False, **batch)
             opt.zero_grad(set_to_none=True)
@@ -92,7 +98,7 @@ def _worker(rank, port, out_dir, grad_sync):
         torch.cuda.synchronize()
         assert all(l == l for l in losses) and int(model.queue_ptr) == 36 and model._side_stream is not None
         # every exchange step went through the collective log (what the hang watchdog reads), all of them completed
-        names = " | ".join(n for _, n, _ in cdist.COLLECTIVES.items)
+        names = " | ".join(it[1] for it in cdist.COLLECTIVES.items)
         assert "all_to_all" in names and "all_gather" in names and (grad_sync != "flat" or "c5 gradient all-reduce, bucket" in names)
         assert cdist.COLLECTIVES.first_incomplete() is None
         torch.save({"losses": losses}, os.path.join(out_dir, "nccl.pt"))
