@@ -72,7 +72,13 @@ __device__ __forceinline__ void bn_bwd_channel(const BnFin& f, int c, int M, int
 // (Letting the last-arriving workgroup of a slice run the epilogue in the same launch was measured and rejected: the
 // agent-scope release it needs is a buffer_wbl2 per workgroup, 46 us per launch instead of 7.  So was letting the
 // apply workgroups of small layers add the partials themselves: the load -> LDS -> math -> LDS prologue costs what the
-// finalize launch costs, 5.6 -> 9.4 us per forward apply, and the 32-chunk cap it needs slows the statistics kernels.)
+// finalize launch costs, 5.6 -> 9.4 us per forward apply, and the 32-chunk cap it needs slows the statistics kernels.
+// Round 4 measured a third form for the 14 x 14 maps (M = 6272): ONE launch in which a 512-thread workgroup owns 16
+// channels over all rows -- the slab held in registers, statistics, epilogue and apply without a partner workgroup.
+// Bit-level tests green, and the training step went from 12.53 to 13.72 ms: C / 16 = 16 ... 128 workgroups pulling 32-byte
+// pieces of 512 ... 4096-byte rows reach a fraction of a CU's bandwidth, so each layer took several times the 16-18 us of
+// the three chip-wide launches it replaced.  Removed; what these layers need is the statistics out of the producing
+// convolution's epilogue.)
 // ---------------------------------------------------------------------------------------------------------------
 template <int MODE, bool RELU>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const u16x8* __restrict__ x, const u16x8* __restrict__ dy,
