@@ -226,7 +226,13 @@ def concat_all_gather(tensor: torch.Tensor) -> torch.Tensor:
 def make_shuffle_index(batch_all: int, device, generator: Optional[torch.Generator] = None) -> torch.Tensor:
     """Shuffle-BN permutation: drawn on the host from the global torch RNG (or `generator`)
     and overwritten with rank 0's by a broadcast, exactly as reference builder.py:618-621."""
-    idx = torch.randperm(batch_all, generator=generator).to(device)
+    idx = torch.randperm(batch_all, generator=generator)
+    if torch.device(device).type == "cuda":
+        # page-locked source + non_blocking, as ShufflePlan's tables: the blocking copy of a pageable tensor cost the DenseCL
+        # step 0.6 ms of host time per call (tools/host_profile.py ... cfg5), on a step that is host-bound
+        idx = idx.pin_memory().to(device, non_blocking=True)
+    else:
+        idx = idx.to(device)
     if multi():
         dist.broadcast(idx, src=0)
     return idx

@@ -1,6 +1,6 @@
 """Host-side cost of one training step: cProfile over the bench configuration's steps (no device synchronisation inside the
 profiled region, so what is counted is the time the CPU needs to ENQUEUE a step -- bench.py's host_issue_ms_per_step).
-usage: python tools/host_profile.py [steps=30] [top=45]"""
+usage: python tools/host_profile.py [steps=30] [top=45] [cfg2|cfg5]"""
 import cProfile
 import contextlib
 import os
@@ -23,10 +23,14 @@ top = int(sys.argv[2]) if len(sys.argv) > 2 else 45
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 torch.backends.cudnn.benchmark = True
-cfg = Config.fromfile(os.path.join(ROOT, "configs", "config_pretrain_r50_fcn.py"))
+workload = sys.argv[3] if len(sys.argv) > 3 else "cfg2"
+densecl = workload == "cfg5"                       # BASELINE configs[4]: DenseCL on the backbone of configs/config_pretrain.py
+cfg = Config.fromfile(os.path.join(ROOT, "configs", "config_pretrain.py" if densecl else "config_pretrain_r50_fcn.py"))
+extra = dict(instance_logits_temp=0.2, dense_logits_temp=0.2, lmbd_cp2_dense_loss=0.5) if densecl else {}
 with contextlib.redirect_stdout(sys.stderr):
-    model = builder.MODEL(cfg, rank=0, K=65536, pretrain_from_scratch=True, pretrain_type=PretrainType.CP2, device=dev,
-                          amp_dtype=torch.bfloat16, channels_last=True).to(dev).train()
+    model = builder.MODEL(cfg, rank=0, K=65536, pretrain_from_scratch=True,
+                          pretrain_type=PretrainType.DENSECL if densecl else PretrainType.CP2, device=dev,
+                          amp_dtype=torch.bfloat16, channels_last=True, **extra).to(dev).train()
 model.encoder_q.to(memory_format=torch.channels_last)
 model.encoder_k.to(memory_format=torch.channels_last)
 opt = FlatSGD(model, 0.03, momentum=0.9, weight_decay=1e-4)
@@ -50,6 +54,13 @@ def timed(name, fn):
 
 
 model._encode_key = timed("key encoder (hipGraph replay)", model._encode_key)
+model._key_forward = timed("key pass (hipGraph replay)", model._key_forward) if densecl else model._key_forward
+if densecl:
+    model.encoder_q.backbone.forward = timed("query backbone forward", model.encoder_q.backbone.forward)
+    model.encoder_q.neck.forward = timed("query neck forward", model.encoder_q.neck.forward)
+    builder.densecl_local_positives = timed("positive selection (cp2_densecl_match)", builder.densecl_local_positives)
+    builder.queue_infonce = timed("queue_infonce (global + local, statistics)", builder.queue_infonce)
+    model._log_step = timed("_log_step", model._log_step)
 model._momentum_update_key_encoder = timed("EMA", model._momentum_update_key_encoder)
 model.encoder_q.forward = timed("query encoder forward", model.encoder_q.forward)
 opt.step = timed("optimizer step", opt.step)
