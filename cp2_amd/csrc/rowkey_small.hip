@@ -238,9 +238,6 @@ __global__ __launch_bounds__(64 * SM_WAVES) void rowkey_small_kernel(RowKeyArgs 
     for (int ti = 0; ti < tiles_per_wg; ++ti) {
         const int kbase = kfirst + ti * SM_KEYS;
         if (kbase >= a.K) break;
-#ifdef CP2_EXP_HALF
-        if (w >= 4) break;           // experiment: one wave per SIMD only (results incomplete)
-#endif
 
         // product 1: S^T[key = rho(reg, h)][row = r]
         f32x16 acc = {0};
