@@ -40,6 +40,10 @@ sys.path.insert(0, ROOT)
 # are ~40 % slower for these ResNet-50 shapes in bf16 NHWC (measured: 22.1 vs 15.5 ms for the encoder work).
 os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this driver
+# CP2_MIOPEN_DB=1: start from the solver rankings MIOpen wrote on an MI355X for these convolutions (cp2_amd/miopen_db) instead
+# of searching: 57 s less start-up per process, steps 1-2 % slower than a box's own search (cp2_amd/miopen_cache.py) -- off by default
+from cp2_amd.miopen_cache import use_shipped_find_db  # noqa: E402
+MIOPEN_DB = use_shipped_find_db()
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 BF16_DENSE_PEAK_TFLOPS = 2500.0
@@ -559,6 +563,7 @@ def main():
         "vs_baseline": None, "dtype": "bf16" if amp is not None else "f32", "data": "synthetic",
         "config": {"workload": workload,
                    "global_batch": b * world, "parallelism": f"dp{world}", "hipgraph": "key encoder forward only",
+                   "miopen_find_db": "shipped rankings (cp2_amd/miopen_db) + search of anything new" if MIOPEN_DB else "searched at start-up",
                    "final_loss": round(loss_val, 4)},
         # the dominant hand-written kernel of the step by time (cfg2: the optimizer update, then the EMA, first entry of roofline_kernels)
         "roofline": roofline,

@@ -82,3 +82,30 @@ def test_model_constructs_on_cpu_but_refuses_to_run_there():
         m(visualize=False, step=0, new_epoch=False, **batch)
     with pytest.raises(AssertionError):
         builder.MODEL(cfg, rank=0, K=256, pretrain_from_scratch=True, lmbd_pixel_corr_weight=10)   # CP2 mapping asserts weights == 1
+
+
+def test_shipped_miopen_find_db_is_copied_once_and_respects_the_callers_choice(tmp_path, monkeypatch):
+    """cp2_amd.miopen_cache: the shipped MIOpen user databases go to a per-user cache directory (never written in the repo),
+    files already there are kept (MIOpen appends to them); opt-in (CP2_MIOPEN_DB=1), and a caller who set MIOPEN_USER_DB_PATH is left alone."""
+    import os
+    from cp2_amd import miopen_cache as mc
+    shipped = [f for f in os.listdir(mc.SHIPPED) if f.endswith((".udb.txt", ".ufdb.txt"))]
+    assert len(shipped) == 2 and all(f.startswith("gfx950") for f in shipped)
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH", raising=False)
+    monkeypatch.delenv("CP2_MIOPEN_DB", raising=False)
+    monkeypatch.setenv("XDG_CACHE_HOME", str(tmp_path))
+    assert mc.use_shipped_find_db() is None and "MIOPEN_USER_DB_PATH" not in os.environ      # opt-in: off by default
+    monkeypatch.setenv("CP2_MIOPEN_DB", "1")
+    dst = mc.use_shipped_find_db()
+    assert dst == str(tmp_path / "cp2_amd" / "miopen_db") and os.environ["MIOPEN_USER_DB_PATH"] == dst
+    assert sorted(os.listdir(dst)) == sorted(shipped)
+    grown = os.path.join(dst, shipped[0])
+    with open(grown, "a") as f:
+        f.write("appended-by-miopen\n")
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH")
+    assert mc.use_shipped_find_db() == dst and open(grown).read().endswith("appended-by-miopen\n")
+    monkeypatch.setenv("MIOPEN_USER_DB_PATH", "/somewhere/else")
+    assert mc.use_shipped_find_db() is None and os.environ["MIOPEN_USER_DB_PATH"] == "/somewhere/else"
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH")
+    monkeypatch.setenv("CP2_MIOPEN_DB", "0")
+    assert mc.use_shipped_find_db() is None and "MIOPEN_USER_DB_PATH" not in os.environ
