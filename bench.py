@@ -40,8 +40,9 @@ sys.path.insert(0, ROOT)
 # are ~40 % slower for these ResNet-50 shapes in bf16 NHWC (measured: 22.1 vs 15.5 ms for the encoder work).
 os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this driver
-# CP2_MIOPEN_DB=1: start from the solver rankings MIOpen wrote on an MI355X for these convolutions (cp2_amd/miopen_db) instead
-# of searching: 57 s less start-up per process, steps 1-2 % slower than a box's own search (cp2_amd/miopen_cache.py) -- off by default
+# ... starting from the solver rankings MIOpen wrote on an MI355X for these convolutions (cp2_amd/miopen_db) instead of searching
+# them again: the same step time (same-box A/B), 57 s less start-up per process, no W concurrent searches at N > 1
+# (cp2_amd/miopen_cache.py; CP2_MIOPEN_DB=0 searches)
 from cp2_amd.miopen_cache import use_shipped_find_db  # noqa: E402
 MIOPEN_DB = use_shipped_find_db()
 

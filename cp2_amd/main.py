@@ -15,7 +15,7 @@ import os
 
 os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")   # short MIOpen solver search; see bench.py
 from .miopen_cache import use_shipped_find_db  # noqa: E402
-use_shipped_find_db()                               # CP2_MIOPEN_DB=1: start from the shipped solver rankings (miopen_cache.py)
+use_shipped_find_db()                               # start from the shipped solver rankings (miopen_cache.py; CP2_MIOPEN_DB=0: search)
 
 import argparse
 import math

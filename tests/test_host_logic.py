@@ -86,7 +86,7 @@ def test_model_constructs_on_cpu_but_refuses_to_run_there():
 
 def test_shipped_miopen_find_db_is_copied_once_and_respects_the_callers_choice(tmp_path, monkeypatch):
     """cp2_amd.miopen_cache: the shipped MIOpen user databases go to a per-user cache directory (never written in the repo),
-    files already there are kept (MIOpen appends to them); opt-in (CP2_MIOPEN_DB=1), and a caller who set MIOPEN_USER_DB_PATH is left alone."""
+    files already there are kept (MIOpen appends to them), and a caller who set MIOPEN_USER_DB_PATH or CP2_MIOPEN_DB=0 is left alone."""
     import os
     from cp2_amd import miopen_cache as mc
     shipped = [f for f in os.listdir(mc.SHIPPED) if f.endswith((".udb.txt", ".ufdb.txt"))]
@@ -94,8 +94,6 @@ def test_shipped_miopen_find_db_is_copied_once_and_respects_the_callers_choice(t
     monkeypatch.delenv("MIOPEN_USER_DB_PATH", raising=False)
     monkeypatch.delenv("CP2_MIOPEN_DB", raising=False)
     monkeypatch.setenv("XDG_CACHE_HOME", str(tmp_path))
-    assert mc.use_shipped_find_db() is None and "MIOPEN_USER_DB_PATH" not in os.environ      # opt-in: off by default
-    monkeypatch.setenv("CP2_MIOPEN_DB", "1")
     dst = mc.use_shipped_find_db()
     assert dst == str(tmp_path / "cp2_amd" / "miopen_db") and os.environ["MIOPEN_USER_DB_PATH"] == dst
     assert sorted(os.listdir(dst)) == sorted(shipped)
